@@ -1,0 +1,738 @@
+// aix_api.hip — the C ABI of libaindex_hip.so (include/aindex_hip.h): index lifecycle in HBM,
+// host<->device staging, launch glue. No CPU compute path exists behind these entry points.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/aindex_hip.h"
+#include "aix_internal.hpp"
+
+using namespace aix;
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            set_last_error(std::string(#expr) + ": " + hipGetErrorString(_e));                \
+            return AIX_ERR_HIP;                                                               \
+        }                                                                                     \
+    } while (0)
+
+static thread_local std::string g_last_error;
+static void set_last_error(const std::string& s) { g_last_error = s; }
+
+struct DevGuard {   // switch to the handle's device for the duration of a call, then restore
+    int prev = -1;
+    bool ok = false;
+    explicit DevGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+struct aix_index {
+    int device = 0;
+    uint32_t k = 0;
+    uint64_t n = 0;
+    // .pf header
+    uint64_t mphf_n = 0, D = 0, seed = 0, B = 0, W = 0;
+    // HBM
+    BvRec* recs = nullptr;
+    KeyRec* keys = nullptr;
+    uint64_t* tf13_mphf = nullptr;
+    uint64_t* tf13_code = nullptr;
+    uint32_t* perm13 = nullptr;
+    unsigned long long* scratch13 = nullptr;   // code-ordered count table, lazily allocated
+    uint64_t device_bytes = 0;
+    bool canonical_only = false;
+    bool canonical_fastpath = true;
+    std::mutex count_mutex;
+
+    IndexDev dev() const {
+        IndexDev d{};
+        d.m.recs = recs;
+        d.m.D = D;
+        d.m.seed = seed;
+        d.m.nrecs = W;
+        d.m.fm = make_fastmod(D);
+        d.keys = keys;
+        d.n = n;
+        d.tf13_code = tf13_code;
+        d.tf13_mphf = tf13_mphf;
+        d.canonical_only = (canonical_only && canonical_fastpath) ? 1u : 0u;
+        d.k = k;
+        return d;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
+extern "C" const char* aix_version(void) { return "aindex_hip 0.1.0 (gfx950)"; }
+
+extern "C" const char* aix_strerror(int st) {
+    switch (st) {
+        case AIX_OK: return "ok";
+        case AIX_ERR_ARG: return "invalid argument";
+        case AIX_ERR_IO: return "file missing, unreadable or short";
+        case AIX_ERR_FORMAT: return "malformed index file";
+        case AIX_ERR_NOMEM: return "out of memory";
+        case AIX_ERR_HIP: return g_last_error.empty() ? "HIP runtime error / no device" : g_last_error.c_str();
+        case AIX_ERR_UNSUPPORTED: return "unsupported size or configuration";
+        case AIX_ERR_MODE: return "call does not match the handle's k-mer mode";
+        case AIX_ERR_CONFLICT: return "hash conflict while scattering (key not in the MPHF set)";
+        default: return "unknown status";
+    }
+}
+
+extern "C" int aix_device_count(int* count) {
+    if (!count) return AIX_ERR_ARG;
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess || c <= 0) {
+        *count = 0;
+        set_last_error(std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+        return AIX_ERR_HIP;
+    }
+    *count = c;
+    return AIX_OK;
+}
+
+extern "C" uint64_t aix_selftest_mod(uint64_t h, uint64_t d) { return fastmod(h, make_fastmod(d)); }
+extern "C" uint64_t aix_selftest_revcomp(uint64_t code, int k) { return revcomp(code, k); }
+
+// ---------------------------------------------------------------------------------------------
+// files
+// ---------------------------------------------------------------------------------------------
+struct MappedFile {
+    const uint8_t* p = nullptr;
+    uint64_t len = 0;
+    int open(const char* path) {
+        int fd = ::open(path, O_RDONLY);
+        if (fd < 0) return AIX_ERR_IO;
+        struct stat st;
+        if (fstat(fd, &st) != 0) { ::close(fd); return AIX_ERR_IO; }
+        len = (uint64_t)st.st_size;
+        if (len) {
+            void* m = mmap(nullptr, len, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) { ::close(fd); return AIX_ERR_IO; }
+            p = (const uint8_t*)m;
+        }
+        ::close(fd);
+        return AIX_OK;
+    }
+    ~MappedFile() { if (p) munmap((void*)p, len); }
+};
+
+// parse a .pf image (mphf.hpp:99-113) and lay it out as BvRec records in HBM
+static int upload_mphf(aix_index* h, const uint8_t* pf, uint64_t len) {
+    if (len < 32) return AIX_ERR_FORMAT;
+    uint64_t hdr[4];
+    memcpy(hdr, pf, 32);
+    h->mphf_n = hdr[0]; h->D = hdr[1]; h->seed = hdr[2]; h->B = hdr[3];
+    if (h->B != 3 * h->D) return AIX_ERR_FORMAT;
+    h->W = (h->B + 31) / 32;
+    const uint64_t R = (h->B + 511) / 512;
+    if (len < 32 + 8 * (h->W + R)) return AIX_ERR_FORMAT;
+    if (h->mphf_n >> 32) return AIX_ERR_UNSUPPORTED;          // 32-bit rank prefixes
+    const uint64_t* words = (const uint64_t*)(pf + 32);
+    std::vector<BvRec> recs;
+    try { recs.resize(h->W ? h->W : 1); } catch (const std::bad_alloc&) { return AIX_ERR_NOMEM; }
+    uint64_t run = 0;
+    for (uint64_t i = 0; i < h->W; ++i) {
+        uint64_t w;
+        memcpy(&w, words + i, 8);
+        recs[i].word = w;
+        recs[i].prefix = (uint32_t)run;
+        recs[i].pad = 0;
+        run += popc_pairs(w);
+    }
+    if (run >> 32) return AIX_ERR_UNSUPPORTED;
+    const uint64_t bytes = sizeof(BvRec) * recs.size();
+    HIPCHK(hipMalloc((void**)&h->recs, bytes));
+    h->device_bytes += bytes;
+    HIPCHK(hipMemcpy(h->recs, recs.data(), bytes, hipMemcpyHostToDevice));
+    return AIX_OK;
+}
+
+static int check_device(int device) {
+    int c = 0;
+    int st = aix_device_count(&c);
+    if (st) return st;
+    if (device < 0 || device >= c) return AIX_ERR_ARG;
+    return AIX_OK;
+}
+
+static void destroy(aix_index* h) {
+    if (!h) return;
+    DevGuard g(h->device);
+    if (h->recs) (void)hipFree(h->recs);
+    if (h->keys) (void)hipFree(h->keys);
+    if (h->tf13_mphf) (void)hipFree(h->tf13_mphf);
+    if (h->tf13_code) (void)hipFree(h->tf13_code);
+    if (h->perm13) (void)hipFree(h->perm13);
+    if (h->scratch13) (void)hipFree(h->scratch13);
+    delete h;
+}
+
+extern "C" int aix_index_create_23(const void* pf_bytes, uint64_t pf_len, const uint64_t* checker, const uint32_t* tf, uint64_t n, int device,
+                                   aix_index_t** out) {
+    if (!pf_bytes || !out || (n && (!checker || !tf))) return AIX_ERR_ARG;
+    *out = nullptr;
+    int st = check_device(device);
+    if (st) return st;
+    if (n >> 32) return AIX_ERR_UNSUPPORTED;
+    aix_index* h = new (std::nothrow) aix_index();
+    if (!h) return AIX_ERR_NOMEM;
+    h->device = device; h->k = 23; h->n = n;
+    DevGuard g(device);
+    auto fail = [&](int code) { destroy(h); return code; };
+    st = upload_mphf(h, (const uint8_t*)pf_bytes, pf_len);
+    if (st) return fail(st);
+    if (n) {
+        uint64_t* d_checker = nullptr; uint32_t* d_tf = nullptr; uint32_t* d_flag = nullptr;
+        hipError_t e = hipMalloc((void**)&h->keys, sizeof(KeyRec) * n);
+        if (e == hipSuccess) e = hipMalloc((void**)&d_checker, 8 * n);
+        if (e == hipSuccess) e = hipMalloc((void**)&d_tf, 4 * n);
+        if (e == hipSuccess) e = hipMalloc((void**)&d_flag, 4);
+        if (e == hipSuccess) e = hipMemcpy(d_checker, checker, 8 * n, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_tf, tf, 4 * n, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemset(d_flag, 0, 4);
+        if (e == hipSuccess) e = launch_build_keyrecs(d_checker, d_tf, n, h->keys, d_flag, 0);
+        uint32_t flag = 1;
+        if (e == hipSuccess) e = hipMemcpy(&flag, d_flag, 4, hipMemcpyDeviceToHost);
+        if (d_checker) (void)hipFree(d_checker);
+        if (d_tf) (void)hipFree(d_tf);
+        if (d_flag) (void)hipFree(d_flag);
+        if (e != hipSuccess) { set_last_error(std::string("index upload: ") + hipGetErrorString(e)); return fail(AIX_ERR_HIP); }
+        h->device_bytes += sizeof(KeyRec) * n;
+        h->canonical_only = (flag == 0);
+    }
+    *out = h;
+    return AIX_OK;
+}
+
+extern "C" int aix_index_open_23(const char* pf, const char* tf_bin, const char* kmers_bin, int device, aix_index_t** out) {
+    if (!pf || !tf_bin || !kmers_bin || !out) return AIX_ERR_ARG;
+    MappedFile fpf, ftf, fk;
+    if (fpf.open(pf) || ftf.open(tf_bin) || fk.open(kmers_bin)) return AIX_ERR_IO;
+    const uint64_t n = fk.len / 8;                              // hash.cpp:393-397: n = size(.kmers.bin)/8
+    std::vector<uint32_t> tfpad;
+    const uint32_t* tfp = (const uint32_t*)ftf.p;
+    if (ftf.len / 4 < n) {                                      // hash.cpp:431-444 reads until EOF; rest stays 0
+        tfpad.assign(n, 0);
+        memcpy(tfpad.data(), ftf.p, (ftf.len / 4) * 4);
+        tfp = tfpad.data();
+    }
+    return aix_index_create_23(fpf.p, fpf.len, (const uint64_t*)fk.p, tfp, n, device, out);
+}
+
+static int build_13_tables(aix_index* h, const uint64_t* tf_host) {
+    const uint64_t N13 = AIX_TOTAL_13MERS;
+    HIPCHK(hipMalloc((void**)&h->tf13_mphf, 8 * N13));
+    HIPCHK(hipMalloc((void**)&h->tf13_code, 8 * N13));
+    HIPCHK(hipMalloc((void**)&h->perm13, 4 * N13));
+    h->device_bytes += 20 * N13;
+    if (tf_host) HIPCHK(hipMemcpy(h->tf13_mphf, tf_host, 8 * N13, hipMemcpyHostToDevice));
+    else HIPCHK(hipMemset(h->tf13_mphf, 0, 8 * N13));
+    const IndexDev d = h->dev();
+    HIPCHK(launch_perm13(d.m, h->perm13, 0));
+    HIPCHK(launch_tf13_to_code_order(h->perm13, h->tf13_mphf, h->tf13_code, 0));
+    HIPCHK(hipStreamSynchronize(0));
+    return AIX_OK;
+}
+
+extern "C" int aix_index_create_13(const void* pf_bytes, uint64_t pf_len, const uint64_t* tf, int device, aix_index_t** out) {
+    if (!pf_bytes || !out) return AIX_ERR_ARG;
+    *out = nullptr;
+    int st = check_device(device);
+    if (st) return st;
+    aix_index* h = new (std::nothrow) aix_index();
+    if (!h) return AIX_ERR_NOMEM;
+    h->device = device; h->k = 13; h->n = AIX_TOTAL_13MERS;
+    DevGuard g(device);
+    st = upload_mphf(h, (const uint8_t*)pf_bytes, pf_len);
+    if (!st) st = build_13_tables(h, tf);
+    if (st) { destroy(h); return st; }
+    *out = h;
+    return AIX_OK;
+}
+
+extern "C" int aix_index_open_13(const char* pf, const char* tf_bin, int device, aix_index_t** out) {
+    if (!pf || !out) return AIX_ERR_ARG;
+    MappedFile fpf, ftf;
+    if (fpf.open(pf)) return AIX_ERR_IO;
+    const uint64_t* tf = nullptr;
+    if (tf_bin) {
+        if (ftf.open(tf_bin)) return AIX_ERR_IO;
+        if (ftf.len < 8 * AIX_TOTAL_13MERS) return AIX_ERR_FORMAT;   // reference mmaps 4^13*8 bytes (:425)
+        tf = (const uint64_t*)ftf.p;
+    }
+    return aix_index_create_13(fpf.p, fpf.len, tf, device, out);
+}
+
+extern "C" int aix_index_close(aix_index_t* h) {
+    if (!h) return AIX_ERR_ARG;
+    destroy(h);
+    return AIX_OK;
+}
+
+extern "C" int aix_index_info(const aix_index_t* h, aix_info_t* info) {
+    if (!h || !info) return AIX_ERR_ARG;
+    memset(info, 0, sizeof(*info));
+    info->k = h->k; info->device = (uint32_t)h->device; info->n = h->n; info->mphf_n = h->mphf_n;
+    info->hash_domain = h->D; info->seed = h->seed; info->bitpairs = h->B; info->device_bytes = h->device_bytes;
+    info->canonical_only = h->canonical_only ? 1 : 0;
+    return AIX_OK;
+}
+
+extern "C" int aix_index_set_canonical_fastpath(aix_index_t* h, int enabled) {
+    if (!h) return AIX_ERR_ARG;
+    h->canonical_fastpath = enabled != 0;
+    return AIX_OK;
+}
+
+extern "C" int aix_index_set_tf_13(aix_index_t* h, const uint64_t* tf) {
+    if (!h || !tf) return AIX_ERR_ARG;
+    if (h->k != 13) return AIX_ERR_MODE;
+    DevGuard g(h->device);
+    HIPCHK(hipMemcpy(h->tf13_mphf, tf, 8 * AIX_TOTAL_13MERS, hipMemcpyHostToDevice));
+    HIPCHK(launch_tf13_to_code_order(h->perm13, h->tf13_mphf, h->tf13_code, 0));
+    HIPCHK(hipStreamSynchronize(0));
+    return AIX_OK;
+}
+
+extern "C" int aix_index_get_tf(const aix_index_t* h, void* out, uint64_t out_bytes) {
+    if (!h || !out) return AIX_ERR_ARG;
+    DevGuard g(h->device);
+    if (h->k == 13) {
+        if (out_bytes < 8 * AIX_TOTAL_13MERS) return AIX_ERR_ARG;
+        HIPCHK(hipMemcpy(out, h->tf13_mphf, 8 * AIX_TOTAL_13MERS, hipMemcpyDeviceToHost));
+        return AIX_OK;
+    }
+    if (out_bytes < 4 * h->n) return AIX_ERR_ARG;
+    if (h->n == 0) return AIX_OK;
+    uint32_t* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, 4 * h->n));
+    hipError_t e = launch_extract_tf(h->keys, h->n, d, nullptr, 0);
+    if (e == hipSuccess) e = hipMemcpy(out, d, 4 * h->n, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    HIPCHK(e);
+    return AIX_OK;
+}
+
+extern "C" int aix_index_get_checker(const aix_index_t* h, uint64_t* out, uint64_t n) {
+    if (!h || !out) return AIX_ERR_ARG;
+    if (h->k != 23) return AIX_ERR_MODE;
+    if (n < h->n) return AIX_ERR_ARG;
+    if (h->n == 0) return AIX_OK;
+    DevGuard g(h->device);
+    uint64_t* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, 8 * h->n));
+    hipError_t e = launch_extract_tf(h->keys, h->n, nullptr, d, 0);
+    if (e == hipSuccess) e = hipMemcpy(out, d, 8 * h->n, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    HIPCHK(e);
+    return AIX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device-pointer entry points
+// ---------------------------------------------------------------------------------------------
+static int lookup_ascii_dev(aix_index_t* h, const char* d_kmers, uint64_t N, int mode, LookupOut o, void* stream) {
+    if (!h || (N && !d_kmers)) return AIX_ERR_ARG;
+    if (N == 0) return AIX_OK;
+    DevGuard g(h->device);
+    const IndexDev d = h->dev();
+    if (h->k == 23) {
+        if (h->n == 0) {                                       // empty index: every answer is 0
+            return AIX_ERR_UNSUPPORTED;
+        }
+        HIPCHK(launch_lookup23_ascii(d, (const uint8_t*)d_kmers, N, mode, o, (hipStream_t)stream));
+    } else {
+        if (mode == MODE_HASH || mode == MODE_KIDSTRAND) return AIX_ERR_MODE;   // hash_map is null in 13-mer mode
+        HIPCHK(launch_lookup13_ascii(d, (const uint8_t*)d_kmers, N, mode, o, (hipStream_t)stream));
+    }
+    return AIX_OK;
+}
+
+extern "C" int aix_tf_batch_ascii_dev(aix_index_t* h, const char* d_kmers, uint64_t N, uint32_t* d_out, void* stream) {
+    if (N && !d_out) return AIX_ERR_ARG;
+    LookupOut o{};
+    o.tf = d_out;
+    return lookup_ascii_dev(h, d_kmers, N, MODE_TF, o, stream);
+}
+extern "C" int aix_hash_batch_ascii_dev(aix_index_t* h, const char* d_kmers, uint64_t N, uint64_t* d_out, void* stream) {
+    if (N && !d_out) return AIX_ERR_ARG;
+    LookupOut o{};
+    o.u64a = d_out;
+    return lookup_ascii_dev(h, d_kmers, N, MODE_HASH, o, stream);
+}
+extern "C" int aix_kid_strand_batch_ascii_dev(aix_index_t* h, const char* d_kmers, uint64_t N, uint64_t* d_kid, uint8_t* d_strand, void* stream) {
+    LookupOut o{};
+    o.u64a = d_kid; o.strand = d_strand;
+    return lookup_ascii_dev(h, d_kmers, N, MODE_KIDSTRAND, o, stream);
+}
+extern "C" int aix_tf_both_batch_ascii_dev(aix_index_t* h, const char* d_kmers, uint64_t N, uint64_t* d_fwd, uint64_t* d_rc, void* stream) {
+    LookupOut o{};
+    o.u64a = d_fwd; o.u64b = d_rc;
+    return lookup_ascii_dev(h, d_kmers, N, MODE_BOTH, o, stream);
+}
+extern "C" int aix_tf_total_batch_ascii_dev(aix_index_t* h, const char* d_kmers, uint64_t N, uint64_t* d_out, void* stream) {
+    if (N && !d_out) return AIX_ERR_ARG;
+    LookupOut o{};
+    o.u64a = d_out;
+    return lookup_ascii_dev(h, d_kmers, N, MODE_TOTAL, o, stream);
+}
+extern "C" int aix_tf_batch_codes_dev(aix_index_t* h, const uint64_t* d_codes, uint64_t N, uint32_t* d_out, void* stream) {
+    if (!h || (N && (!d_codes || !d_out))) return AIX_ERR_ARG;
+    if (h->k != 23) return AIX_ERR_MODE;
+    if (N == 0) return AIX_OK;
+    if (h->n == 0) return AIX_ERR_UNSUPPORTED;
+    DevGuard g(h->device);
+    HIPCHK(launch_lookup23_codes(h->dev(), d_codes, N, d_out, (hipStream_t)stream));
+    return AIX_OK;
+}
+extern "C" int aix_tf_batch_ragged_dev(aix_index_t* h, const char* d_bytes, const uint64_t* d_offs, uint64_t N, uint32_t* d_out, void* stream) {
+    if (!h || (N && (!d_offs || !d_out))) return AIX_ERR_ARG;
+    if (N == 0) return AIX_OK;
+    DevGuard g(h->device);
+    if (h->k == 23) {
+        if (h->n == 0) return AIX_ERR_UNSUPPORTED;
+        HIPCHK(launch_lookup23_ragged(h->dev(), (const uint8_t*)d_bytes, d_offs, N, d_out, (hipStream_t)stream));
+    } else {
+        HIPCHK(launch_lookup13_ragged(h->dev(), (const uint8_t*)d_bytes, d_offs, N, d_out, (hipStream_t)stream));
+    }
+    return AIX_OK;
+}
+extern "C" int aix_coverage_batch_dev(aix_index_t* h, const char* d_seqs, const uint64_t* d_offs, uint64_t M, uint64_t total_bytes, uint32_t cutoff,
+                                      uint32_t* d_out, const uint64_t* d_out_offs, void* stream) {
+    if (!h || (M && (!d_seqs || !d_offs || !d_out || !d_out_offs))) return AIX_ERR_ARG;
+    if (M == 0 || total_bytes == 0) return AIX_OK;
+    if (h->k == 23 && h->n == 0) return AIX_ERR_UNSUPPORTED;
+    DevGuard g(h->device);
+    HIPCHK(launch_coverage(h->dev(), (const uint8_t*)d_seqs, d_offs, M, total_bytes, cutoff, d_out, d_out_offs, (hipStream_t)stream));
+    return AIX_OK;
+}
+
+extern "C" int aix_count13_dev(aix_index_t* h, const char* d_plain, uint64_t len, uint64_t* d_tf_out, void* stream) {
+    if (!h || !d_tf_out || (len && !d_plain)) return AIX_ERR_ARG;
+    if (h->k != 13) return AIX_ERR_MODE;
+    DevGuard g(h->device);
+    std::lock_guard<std::mutex> lk(h->count_mutex);
+    if (!h->scratch13) {
+        HIPCHK(hipMalloc((void**)&h->scratch13, 8 * AIX_TOTAL_13MERS));
+        h->device_bytes += 8 * AIX_TOTAL_13MERS;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipMemsetAsync(h->scratch13, 0, 8 * AIX_TOTAL_13MERS, s));
+    HIPCHK(hipMemsetAsync(d_tf_out, 0, 8 * AIX_TOTAL_13MERS, s));
+    HIPCHK(launch_count13_plain((const uint8_t*)d_plain, len, h->scratch13, s));
+    HIPCHK(launch_scatter13_to_mphf(h->perm13, h->scratch13, d_tf_out, s));
+    return AIX_OK;
+}
+
+extern "C" int aix_count23_fixed_dev(aix_index_t* h, const char* d_plain, uint64_t len, int canon_mode, uint32_t* d_tf_out, void* stream) {
+    if (!h || !d_tf_out || (len && !d_plain)) return AIX_ERR_ARG;
+    if (h->k != 23) return AIX_ERR_MODE;
+    if (canon_mode < 0 || canon_mode > 2) return AIX_ERR_ARG;
+    DevGuard g(h->device);
+    HIPCHK(launch_count23_fixed(h->dev(), (const uint8_t*)d_plain, len, canon_mode, d_tf_out, (hipStream_t)stream));
+    return AIX_OK;
+}
+
+extern "C" int aix_synth_genome_dev(uint64_t seed, uint64_t length, char* d_out, void* stream) {
+    if (length && !d_out) return AIX_ERR_ARG;
+    HIPCHK(launch_synth_genome(seed, length, (uint8_t*)d_out, (hipStream_t)stream));
+    return AIX_OK;
+}
+extern "C" int aix_synth_kmers_dev(uint64_t seed, uint64_t first, uint64_t N, int k, char* d_out, void* stream) {
+    if ((N && !d_out) || k < 1 || k > 32) return AIX_ERR_ARG;
+    HIPCHK(launch_synth_kmers(seed, first, N, k, (uint8_t*)d_out, (hipStream_t)stream));
+    return AIX_OK;
+}
+extern "C" int aix_synth_reads_dev(uint64_t seed, const char* d_genome, uint64_t genome_len, uint64_t first_read, uint64_t n_reads, uint32_t read_len,
+                                   int rc_half, uint32_t n_rate_ppm, char* d_out, void* stream) {
+    if (!d_genome || (n_reads && !d_out) || read_len == 0 || genome_len < read_len) return AIX_ERR_ARG;
+    HIPCHK(launch_synth_reads(seed, (const uint8_t*)d_genome, genome_len, first_read, n_reads, read_len, rc_half, n_rate_ppm, (uint8_t*)d_out,
+                              (hipStream_t)stream));
+    return AIX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-pointer twins: stage through HBM in bounded chunks, run the same kernels, copy back
+// ---------------------------------------------------------------------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    hipError_t alloc(uint64_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+static constexpr uint64_t kChunk = 1ull << 26;   // queries per staging chunk (64 Mi)
+
+template <typename F>
+static int chunked_ascii(aix_index_t* h, const char* kmers, uint64_t N, uint32_t out_elem_bytes[3], void* outs[3], F&& call) {
+    if (!h || (N && !kmers)) return AIX_ERR_ARG;
+    if (N == 0) return AIX_OK;
+    DevGuard g(h->device);
+    const uint64_t k = h->k, chunk = std::min<uint64_t>(N, kChunk);
+    DevBuf dq, d0, d1, d2;
+    HIPCHK(dq.alloc(chunk * k + 8));
+    DevBuf* douts[3] = {&d0, &d1, &d2};
+    for (int j = 0; j < 3; ++j)
+        if (outs[j]) HIPCHK(douts[j]->alloc(chunk * out_elem_bytes[j]));
+    for (uint64_t lo = 0; lo < N; lo += chunk) {
+        const uint64_t m = std::min(chunk, N - lo);
+        HIPCHK(hipMemcpy(dq.p, kmers + lo * k, m * k, hipMemcpyHostToDevice));
+        int st = call((const char*)dq.p, m, d0.p, d1.p, d2.p);
+        if (st) return st;
+        HIPCHK(hipStreamSynchronize(0));
+        for (int j = 0; j < 3; ++j)
+            if (outs[j]) HIPCHK(hipMemcpy((char*)outs[j] + lo * out_elem_bytes[j], douts[j]->p, m * out_elem_bytes[j], hipMemcpyDeviceToHost));
+    }
+    return AIX_OK;
+}
+
+static bool empty23(const aix_index_t* h) { return h && h->k == 23 && h->n == 0; }
+
+extern "C" int aix_tf_batch_ascii(aix_index_t* h, const char* kmers, uint64_t N, uint32_t* out) {
+    if (N && !out) return AIX_ERR_ARG;
+    if (empty23(h)) { memset(out, 0, 4 * N); return AIX_OK; }
+    uint32_t eb[3] = {4, 0, 0};
+    void* outs[3] = {out, nullptr, nullptr};
+    return chunked_ascii(h, kmers, N, eb, outs, [&](const char* dq, uint64_t m, void* a, void*, void*) {
+        return aix_tf_batch_ascii_dev(h, dq, m, (uint32_t*)a, nullptr);
+    });
+}
+extern "C" int aix_hash_batch_ascii(aix_index_t* h, const char* kmers, uint64_t N, uint64_t* out) {
+    if (N && !out) return AIX_ERR_ARG;
+    if (h && h->k != 23) return AIX_ERR_MODE;
+    if (empty23(h)) return AIX_ERR_UNSUPPORTED;
+    uint32_t eb[3] = {8, 0, 0};
+    void* outs[3] = {out, nullptr, nullptr};
+    return chunked_ascii(h, kmers, N, eb, outs, [&](const char* dq, uint64_t m, void* a, void*, void*) {
+        return aix_hash_batch_ascii_dev(h, dq, m, (uint64_t*)a, nullptr);
+    });
+}
+extern "C" int aix_kid_strand_batch_ascii(aix_index_t* h, const char* kmers, uint64_t N, uint64_t* kid_out, uint8_t* strand_out) {
+    if (h && h->k != 23) return AIX_ERR_MODE;
+    if (empty23(h)) {
+        if (kid_out) memset(kid_out, 0, 8 * N);
+        if (strand_out) memset(strand_out, 0, N);
+        return AIX_OK;
+    }
+    uint32_t eb[3] = {8, 1, 0};
+    void* outs[3] = {kid_out, strand_out, nullptr};
+    return chunked_ascii(h, kmers, N, eb, outs, [&](const char* dq, uint64_t m, void* a, void* b, void*) {
+        return aix_kid_strand_batch_ascii_dev(h, dq, m, kid_out ? (uint64_t*)a : nullptr, strand_out ? (uint8_t*)b : nullptr, nullptr);
+    });
+}
+extern "C" int aix_tf_both_batch_ascii(aix_index_t* h, const char* kmers, uint64_t N, uint64_t* fwd_out, uint64_t* rc_out) {
+    if (empty23(h)) {
+        if (fwd_out) memset(fwd_out, 0, 8 * N);
+        if (rc_out) memset(rc_out, 0, 8 * N);
+        return AIX_OK;
+    }
+    uint32_t eb[3] = {8, 8, 0};
+    void* outs[3] = {fwd_out, rc_out, nullptr};
+    return chunked_ascii(h, kmers, N, eb, outs, [&](const char* dq, uint64_t m, void* a, void* b, void*) {
+        return aix_tf_both_batch_ascii_dev(h, dq, m, fwd_out ? (uint64_t*)a : nullptr, rc_out ? (uint64_t*)b : nullptr, nullptr);
+    });
+}
+extern "C" int aix_tf_total_batch_ascii(aix_index_t* h, const char* kmers, uint64_t N, uint64_t* out) {
+    if (N && !out) return AIX_ERR_ARG;
+    if (empty23(h)) { memset(out, 0, 8 * N); return AIX_OK; }
+    uint32_t eb[3] = {8, 0, 0};
+    void* outs[3] = {out, nullptr, nullptr};
+    return chunked_ascii(h, kmers, N, eb, outs, [&](const char* dq, uint64_t m, void* a, void*, void*) {
+        return aix_tf_total_batch_ascii_dev(h, dq, m, (uint64_t*)a, nullptr);
+    });
+}
+
+extern "C" int aix_tf_batch_codes(aix_index_t* h, const uint64_t* codes, uint64_t N, uint32_t* out) {
+    if (!h || (N && (!codes || !out))) return AIX_ERR_ARG;
+    if (h->k != 23) return AIX_ERR_MODE;
+    if (N == 0) return AIX_OK;
+    if (h->n == 0) { memset(out, 0, 4 * N); return AIX_OK; }
+    DevGuard g(h->device);
+    const uint64_t chunk = std::min<uint64_t>(N, kChunk);
+    DevBuf dc, dout;
+    HIPCHK(dc.alloc(chunk * 8));
+    HIPCHK(dout.alloc(chunk * 4));
+    for (uint64_t lo = 0; lo < N; lo += chunk) {
+        const uint64_t m = std::min(chunk, N - lo);
+        HIPCHK(hipMemcpy(dc.p, codes + lo, m * 8, hipMemcpyHostToDevice));
+        int st = aix_tf_batch_codes_dev(h, (const uint64_t*)dc.p, m, (uint32_t*)dout.p, nullptr);
+        if (st) return st;
+        HIPCHK(hipStreamSynchronize(0));
+        HIPCHK(hipMemcpy(out + lo, dout.p, m * 4, hipMemcpyDeviceToHost));
+    }
+    return AIX_OK;
+}
+
+extern "C" int aix_tf_batch_ragged(aix_index_t* h, const char* bytes, const uint64_t* offsets, uint64_t N, uint32_t* out) {
+    if (!h || (N && (!offsets || !out))) return AIX_ERR_ARG;
+    if (N == 0) return AIX_OK;
+    if (empty23(h)) { memset(out, 0, 4 * N); return AIX_OK; }
+    const uint64_t base = offsets[0], total = offsets[N] - base;
+    if (total && !bytes) return AIX_ERR_ARG;
+    DevGuard g(h->device);
+    DevBuf db, doffs, dout;
+    HIPCHK(db.alloc(total + 8));
+    HIPCHK(doffs.alloc((N + 1) * 8));
+    HIPCHK(dout.alloc(N * 4));
+    std::vector<uint64_t> rel(N + 1);
+    for (uint64_t i = 0; i <= N; ++i) rel[i] = offsets[i] - base;
+    if (total) HIPCHK(hipMemcpy(db.p, bytes + base, total, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(doffs.p, rel.data(), (N + 1) * 8, hipMemcpyHostToDevice));
+    int st = aix_tf_batch_ragged_dev(h, (const char*)db.p, (const uint64_t*)doffs.p, N, (uint32_t*)dout.p, nullptr);
+    if (st) return st;
+    HIPCHK(hipStreamSynchronize(0));
+    HIPCHK(hipMemcpy(out, dout.p, N * 4, hipMemcpyDeviceToHost));
+    return AIX_OK;
+}
+
+extern "C" int aix_coverage_batch(aix_index_t* h, const char* seqs, const uint64_t* offs, uint64_t M, uint32_t cutoff, uint32_t* out,
+                                  const uint64_t* out_offs) {
+    if (!h || (M && (!seqs || !offs || !out || !out_offs))) return AIX_ERR_ARG;
+    if (M == 0) return AIX_OK;
+    const uint64_t base = offs[0], total = offs[M] - base, obase = out_offs[0], ototal = out_offs[M] - obase;
+    if (ototal == 0) return AIX_OK;
+    if (empty23(h)) { memset(out + obase, 0, 4 * ototal); return AIX_OK; }
+    DevGuard g(h->device);
+    DevBuf ds, doffs, dooffs, dout;
+    HIPCHK(ds.alloc(total + 8));
+    HIPCHK(doffs.alloc((M + 1) * 8));
+    HIPCHK(dooffs.alloc((M + 1) * 8));
+    HIPCHK(dout.alloc(ototal * 4));
+    std::vector<uint64_t> rel(M + 1), orel(M + 1);
+    for (uint64_t i = 0; i <= M; ++i) { rel[i] = offs[i] - base; orel[i] = out_offs[i] - obase; }
+    if (total) HIPCHK(hipMemcpy(ds.p, seqs + base, total, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(doffs.p, rel.data(), (M + 1) * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dooffs.p, orel.data(), (M + 1) * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(dout.p, 0, ototal * 4));
+    int st = aix_coverage_batch_dev(h, (const char*)ds.p, (const uint64_t*)doffs.p, M, total, cutoff, (uint32_t*)dout.p, (const uint64_t*)dooffs.p, nullptr);
+    if (st) return st;
+    HIPCHK(hipStreamSynchronize(0));
+    HIPCHK(hipMemcpy(out + obase, dout.p, ototal * 4, hipMemcpyDeviceToHost));
+    return AIX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// record normalisation (host): readers of count_kmers13.cpp:211-272 and count_kmers.cpp:250-295
+// ---------------------------------------------------------------------------------------------
+extern "C" int aix_detect_format(const char* buf, uint64_t len) {
+    if (!buf || len == 0) return AIX_FMT_PLAIN;
+    if (buf[0] == '\n') return AIX_FMT_PLAIN;
+    if (buf[0] == '>') return AIX_FMT_FASTA;
+    if (buf[0] == '@') return AIX_FMT_FASTQ;
+    return AIX_FMT_PLAIN;
+}
+
+extern "C" int aix_normalize_reads(const char* buf, uint64_t len, int format, int fasta_mode, char* out, uint64_t* out_len) {
+    if (!out || !out_len || (len && !buf)) return AIX_ERR_ARG;
+    if (format == AIX_FMT_AUTO) format = aix_detect_format(buf, len);
+    uint64_t o = 0;
+    if (format == AIX_FMT_PLAIN) {
+        memcpy(out, buf, len);
+        o = len;
+    } else if (format == AIX_FMT_FASTQ) {                      // count_kmers13.cpp:240-257: line 4i+1
+        uint64_t pos = 0, line_no = 0;
+        while (pos < len) {
+            const char* nl = (const char*)memchr(buf + pos, '\n', len - pos);
+            const uint64_t end = nl ? (uint64_t)(nl - buf) : len;
+            if ((line_no & 3) == 1 && end > pos) { memcpy(out + o, buf + pos, end - pos); o += end - pos; out[o++] = '\n'; }
+            line_no++;
+            pos = end + 1;
+        }
+    } else if (format == AIX_FMT_FASTA && fasta_mode == 0) {  // count_kmers13.cpp:211-235
+        uint64_t pos = 0;
+        bool open = false;
+        while (pos < len) {
+            const char* nl = (const char*)memchr(buf + pos, '\n', len - pos);
+            const uint64_t end = nl ? (uint64_t)(nl - buf) : len;
+            if (end > pos) {
+                if (buf[pos] == '>') { if (open) { out[o++] = '\n'; open = false; } }
+                else { memcpy(out + o, buf + pos, end - pos); o += end - pos; open = true; }
+            }
+            pos = end + 1;
+        }
+        if (open) out[o++] = '\n';
+    } else if (format == AIX_FMT_FASTA) {                      // count_kmers.cpp:250-295: '>' anywhere opens a record
+        uint64_t i = 0;
+        while (i < len && buf[i] != '>') i++;
+        while (i < len) {
+            uint64_t end = i + 1;
+            while (end < len && buf[end] != '>') end++;
+            uint64_t j = i;
+            while (j < end && buf[j] != '\n') j++;
+            j++;
+            for (; j < end; ++j) { const char c = buf[j]; if (c != '\n' && c != '\r') out[o++] = c; }
+            out[o++] = '\n';
+            i = end;
+        }
+    } else {
+        return AIX_ERR_ARG;
+    }
+    *out_len = o;
+    return AIX_OK;
+}
+
+static int stage_plain(aix_index_t* h, const char* buf, uint64_t len, int format, int fasta_mode, DevBuf& d, uint64_t& plain_len) {
+    if (format == AIX_FMT_AUTO) format = aix_detect_format(buf, len);
+    const char* src = buf;
+    std::vector<char> tmp;
+    plain_len = len;
+    if (format != AIX_FMT_PLAIN) {
+        try { tmp.resize(len + 2); } catch (const std::bad_alloc&) { return AIX_ERR_NOMEM; }
+        int st = aix_normalize_reads(buf, len, format, fasta_mode, tmp.data(), &plain_len);
+        if (st) return st;
+        src = tmp.data();
+    }
+    HIPCHK(d.alloc(plain_len + 8));
+    if (plain_len) HIPCHK(hipMemcpy(d.p, src, plain_len, hipMemcpyHostToDevice));
+    (void)h;
+    return AIX_OK;
+}
+
+extern "C" int aix_count13(aix_index_t* h, const char* buf, uint64_t len, int format, uint64_t* tf_out) {
+    if (!h || !tf_out || (len && !buf)) return AIX_ERR_ARG;
+    if (h->k != 13) return AIX_ERR_MODE;
+    DevGuard g(h->device);
+    DevBuf d, dout;
+    uint64_t plen = 0;
+    int st = stage_plain(h, buf, len, format, 0, d, plen);
+    if (st) return st;
+    HIPCHK(dout.alloc(8 * AIX_TOTAL_13MERS));
+    st = aix_count13_dev(h, (const char*)d.p, plen, (uint64_t*)dout.p, nullptr);
+    if (st) return st;
+    HIPCHK(hipStreamSynchronize(0));
+    HIPCHK(hipMemcpy(tf_out, dout.p, 8 * AIX_TOTAL_13MERS, hipMemcpyDeviceToHost));
+    return AIX_OK;
+}
+
+extern "C" int aix_count23_fixed(aix_index_t* h, const char* buf, uint64_t len, int format, int canon_mode, uint32_t* tf_out) {
+    if (!h || !tf_out || (len && !buf)) return AIX_ERR_ARG;
+    if (h->k != 23) return AIX_ERR_MODE;
+    if (h->n == 0) return AIX_OK;
+    DevGuard g(h->device);
+    DevBuf d, dout;
+    uint64_t plen = 0;
+    int st = stage_plain(h, buf, len, format, 1, d, plen);
+    if (st) return st;
+    HIPCHK(dout.alloc(4 * h->n));
+    HIPCHK(hipMemset(dout.p, 0, 4 * h->n));
+    st = aix_count23_fixed_dev(h, (const char*)d.p, plen, canon_mode, (uint32_t*)dout.p, nullptr);
+    if (st) return st;
+    HIPCHK(hipStreamSynchronize(0));
+    HIPCHK(hipMemcpy(tf_out, dout.p, 4 * h->n, hipMemcpyDeviceToHost));
+    return AIX_OK;
+}

@@ -1,0 +1,281 @@
+// aix_device.hpp — device-side primitives of the lookup / counting kernels (gfx950).
+//
+// Everything here is integer arithmetic and is also compiled for the host (AIX_HD) so that the CPU
+// test-suite can check the exact-modulo and codec helpers without a GPU (aix_selftest_* in the ABI).
+//
+// Reference semantics restated here (file:line under /root/reference):
+//   jenkins64 / mix          src/emphf/base_hash.hpp:38-91,127-145
+//   mphf::lookup             src/emphf/mphf.hpp:79-89
+//   bitpair get / rank       src/emphf/bitpair_vector.hpp:46-49, ranked_bitpair_vector.hpp:47-62
+//   get_dna23_bitset         src/kmers.cpp:12-40      reverseDNA  src/kmers.cpp:355-388
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define AIX_HD __host__ __device__ __forceinline__
+
+namespace aix {
+
+// ---------------------------------------------------------------------------------------------
+// HBM layouts
+// ---------------------------------------------------------------------------------------------
+// One record per 64-bit word of the emphf bit-pair vector: the word itself plus the number of
+// non-zero pairs in all words before it. rank(pos) = prefix + popc_pairs(word & mask(pos)), so a
+// lookup needs exactly three independent 16-byte reads and no dependent rank-directory read.
+struct __attribute__((aligned(16))) BvRec {
+    uint64_t word;
+    uint32_t prefix;
+    uint32_t pad;
+};
+// checker[] and tf[] of PHASH_MAP (hash.hpp:82-121) interleaved: one 16-byte read per probe.
+struct __attribute__((aligned(16))) KeyRec {
+    uint64_t code;
+    uint32_t tf;
+    uint32_t pad;
+};
+
+// ---------------------------------------------------------------------------------------------
+// exact h % d for a launch-invariant d (Moeller-Granlund 2-by-1 division, 32-bit limbs).
+// gfx950 has no 64-bit integer divide; three of these replace the three `%` of mphf::lookup.
+// ---------------------------------------------------------------------------------------------
+struct FastMod {
+    uint64_t d;      // divisor (m_hash_domain)
+    uint32_t dn;     // d << s, top bit set
+    uint32_t v;      // floor((2^64-1)/dn) - 2^32
+    uint32_t s;      // clz32(d)
+    uint32_t wide;   // d >= 2^32: fall back to the compiler's 64-bit remainder
+};
+
+inline FastMod make_fastmod(uint64_t d) {
+    FastMod f{};
+    f.d = d;
+    if (d == 0) { f.wide = 1; f.d = 1; return f; }
+    if (d >> 32) { f.wide = 1; return f; }
+    uint32_t d32 = (uint32_t)d;
+    f.s = (uint32_t)__builtin_clz(d32);
+    f.dn = d32 << f.s;
+    f.v = (uint32_t)((~0ull) / f.dn - (1ull << 32));
+    return f;
+}
+
+AIX_HD uint32_t rem_2by1(uint32_t u1, uint32_t u0, uint32_t d, uint32_t v) {
+    // precondition u1 < d, d normalised. Returns (u1*2^32 + u0) mod d.
+    uint64_t q = (uint64_t)v * u1 + (((uint64_t)u1 << 32) | u0);
+    uint32_t q1 = (uint32_t)(q >> 32) + 1u, q0 = (uint32_t)q;
+    uint32_t r = u0 - q1 * d;
+    if (r > q0) r += d;
+    if (r >= d) r -= d;
+    return r;
+}
+
+AIX_HD uint64_t fastmod(uint64_t h, const FastMod& f) {
+    if (f.wide) return h % f.d;
+    const uint32_t s = f.s;
+    const uint32_t hi = (uint32_t)(h >> 32), lo = (uint32_t)h;
+    // (u2,u1,u0) = h << s as 96 bits
+    const uint32_t u2 = s ? (hi >> (32 - s)) : 0u;
+    const uint32_t u1 = s ? ((hi << s) | (lo >> (32 - s))) : hi;
+    const uint32_t u0 = lo << s;
+    uint32_t r = rem_2by1(u2, u1, f.dn, f.v);
+    r = rem_2by1(r, u0, f.dn, f.v);
+    return (uint64_t)(r >> s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Jenkins lookup8 mix
+// ---------------------------------------------------------------------------------------------
+AIX_HD void jmix(uint64_t& a, uint64_t& b, uint64_t& c) {
+    a -= b; a -= c; a ^= (c >> 43);
+    b -= c; b -= a; b ^= (a << 9);
+    c -= a; c -= b; c ^= (b >> 8);
+    a -= b; a -= c; a ^= (c >> 38);
+    b -= c; b -= a; b ^= (a << 23);
+    c -= a; c -= b; c ^= (b >> 5);
+    a -= b; a -= c; a ^= (c >> 35);
+    b -= c; b -= a; b ^= (a << 49);
+    c -= a; c -= b; c ^= (b >> 11);
+    a -= b; a -= c; a ^= (c >> 12);
+    b -= c; b -= a; b ^= (a << 18);
+    c -= a; c -= b; c ^= (b >> 22);
+}
+#define AIX_GOLDEN 0x9e3779b97f4a7c13ULL
+
+// hash of a 23-byte key given as little-endian words: w0 = bytes 0-7, w1 = bytes 8-15,
+// w2 = bytes 16-22 (56 bits). base_hash.hpp:57-88 with len = 23 (< 24: no main-loop round).
+AIX_HD void jenkins23(uint64_t w0, uint64_t w1, uint64_t w2, uint64_t seed, uint64_t& a, uint64_t& b, uint64_t& c) {
+    a = seed + w0;
+    b = seed + w1;
+    c = AIX_GOLDEN + 23 + (w2 << 8);
+    jmix(a, b, c);
+}
+// 13-byte key: w0 = bytes 0-7, w1 = bytes 8-12 (40 bits)
+AIX_HD void jenkins13(uint64_t w0, uint64_t w1, uint64_t seed, uint64_t& a, uint64_t& b, uint64_t& c) {
+    a = seed + w0;
+    b = seed + w1;
+    c = AIX_GOLDEN + 13;
+    jmix(a, b, c);
+}
+// arbitrary length, bytes in (global) memory — the slow exact lane for len != k queries
+AIX_HD void jenkins_bytes(const uint8_t* s, uint64_t len, uint64_t seed, uint64_t& a, uint64_t& b, uint64_t& c) {
+    a = seed; b = seed; c = AIX_GOLDEN;
+    uint64_t rem = len;
+    while (rem >= 24) {
+        uint64_t w[3] = {0, 0, 0};
+        for (int i = 0; i < 24; ++i) w[i >> 3] |= (uint64_t)s[i] << (8 * (i & 7));
+        a += w[0]; b += w[1]; c += w[2];
+        jmix(a, b, c);
+        s += 24; rem -= 24;
+    }
+    c += len;
+    for (uint64_t i = 0; i < rem; ++i) {
+        uint64_t v = (uint64_t)s[i];
+        if (i < 8) a += v << (8 * i);
+        else if (i < 16) b += v << (8 * (i - 8));
+        else c += v << (8 * (i - 15));
+    }
+    jmix(a, b, c);
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2-bit codec
+// ---------------------------------------------------------------------------------------------
+AIX_HD uint32_t popc_pairs(uint64_t x) {   // nonzero_pairs(): same value as the broadword form
+    x = (x | (x >> 1)) & 0x5555555555555555ULL;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__popcll(x);
+#else
+    return (uint32_t)__builtin_popcountll(x);
+#endif
+}
+
+// reverse complement of a k-mer code (true rc; equals reverseDNA for k = 23 / 13)
+AIX_HD uint64_t revcomp(uint64_t code, int k) {
+    uint64_t y = __builtin_bitreverse64(code);                     // pairs reversed, bits in a pair swapped
+    y = ((y >> 1) & 0x5555555555555555ULL) | ((y & 0x5555555555555555ULL) << 1);
+    return (~y) >> (64 - 2 * k);
+}
+// kmer_counter's defective rc (count_kmers.cpp:116-130): the first stage swaps the two bits inside
+// every base, so the net effect is reverse + (A<->T, C->C, G->G): plain bit reversal, complement.
+AIX_HD uint64_t revcomp_refx86(uint64_t code, int k) {
+    return (~__builtin_bitreverse64(code)) >> (64 - 2 * k);
+}
+
+// spread 4 pairs (pair i at bits 2i..2i+1 of x) to 4 bytes (byte i = pair i)
+AIX_HD uint32_t spread4(uint32_t x) {
+    x &= 0xffu;
+    x = (x | (x << 12)) & 0x000F000Fu;
+    x = (x | (x << 6)) & 0x03030303u;
+    return x;
+}
+// byte-wise LUT: out.byte[i] = lut.byte[sel.byte[i]] for sel bytes in 0..3
+AIX_HD uint32_t lut4(uint32_t sel, uint32_t lut) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_perm(0u, lut, sel);                    // v_perm_b32
+#else
+    uint32_t r = 0;
+    for (int i = 0; i < 4; ++i) r |= ((lut >> (8 * ((sel >> (8 * i)) & 3))) & 0xffu) << (8 * i);
+    return r;
+#endif
+}
+#define AIX_LUT_ACGT 0x54474341u   // pair value -> 'A','C','G','T'
+#define AIX_LUT_TGCA 0x41434754u   // pair value -> complement base
+
+// ASCII words of the k-mer S whose reverse-complement code is `rc` (S[j] = comp(pair j of rc,
+// counted from the least significant end)): forward string of code u = ascii_of_rc(revcomp(u));
+// reverse-complement string of u = ascii_of_rc(u).
+AIX_HD void ascii23_of_rc(uint64_t rc, uint64_t& w0, uint64_t& w1, uint64_t& w2) {
+    uint32_t lo = (uint32_t)rc, hi = (uint32_t)(rc >> 32);
+    uint32_t d0 = lut4(spread4(lo), AIX_LUT_TGCA);
+    uint32_t d1 = lut4(spread4(lo >> 8), AIX_LUT_TGCA);
+    uint32_t d2 = lut4(spread4(lo >> 16), AIX_LUT_TGCA);
+    uint32_t d3 = lut4(spread4(lo >> 24), AIX_LUT_TGCA);
+    uint32_t d4 = lut4(spread4(hi), AIX_LUT_TGCA);
+    uint32_t d5 = lut4(spread4(hi >> 8), AIX_LUT_TGCA) & 0x00FFFFFFu;
+    w0 = d0 | ((uint64_t)d1 << 32);
+    w1 = d2 | ((uint64_t)d3 << 32);
+    w2 = d4 | ((uint64_t)d5 << 32);
+}
+AIX_HD void ascii13_of_rc(uint32_t rc, uint64_t& w0, uint64_t& w1) {
+    uint32_t d0 = lut4(spread4(rc), AIX_LUT_TGCA);
+    uint32_t d1 = lut4(spread4(rc >> 8), AIX_LUT_TGCA);
+    uint32_t d2 = lut4(spread4(rc >> 16), AIX_LUT_TGCA);
+    uint32_t d3 = lut4(spread4(rc >> 24), AIX_LUT_TGCA) & 0x000000FFu;
+    w0 = d0 | ((uint64_t)d1 << 32);
+    w1 = d2 | ((uint64_t)d3 << 32);
+}
+
+// 4 ASCII bytes -> 4 pairs packed MSB-first into 8 bits, plus a per-byte "not A/C/G/T" mask.
+// Invalid bytes contribute 0 bits exactly like get_dna23_bitset (kmers.cpp:12-25).
+AIX_HD uint32_t encode4(uint32_t x, uint32_t& bad /* 0x01 per invalid byte */) {
+    uint32_t c2 = ((x >> 1) ^ (x >> 2)) & 0x03030303u;
+    uint32_t y = lut4(c2, AIX_LUT_ACGT) ^ x;                       // zero byte <=> valid base
+    uint32_t t = (((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y) & 0x80808080u;
+    bad = t >> 7;
+    c2 &= ~(bad * 3u);
+    return (c2 * 0x40100401u) >> 24;
+}
+
+// words of a raw 23-byte query -> sanitised code + validity
+struct Enc23 {
+    uint64_t code;
+    bool valid;
+};
+AIX_HD Enc23 encode23_words(uint64_t w0, uint64_t w1, uint64_t w2) {
+    uint32_t b0, b1, b2, b3, b4, b5;
+    uint64_t code = encode4((uint32_t)w0, b0);
+    code = (code << 8) | encode4((uint32_t)(w0 >> 32), b1);
+    code = (code << 8) | encode4((uint32_t)w1, b2);
+    code = (code << 8) | encode4((uint32_t)(w1 >> 32), b3);
+    code = (code << 8) | encode4((uint32_t)w2, b4);
+    uint32_t last = encode4((uint32_t)(w2 >> 32), b5);             // 4th byte is 0 -> "invalid", pair 0
+    code = (code << 6) | (last >> 2);
+    Enc23 e;
+    e.code = code;
+    e.valid = ((b0 | b1 | b2 | b3 | b4 | (b5 & 0x00010101u)) == 0);
+    return e;
+}
+struct Enc13 {
+    uint32_t code;
+    bool valid;
+};
+AIX_HD Enc13 encode13_words(uint64_t w0, uint64_t w1) {
+    uint32_t b0, b1, b2, b3;
+    uint32_t code = encode4((uint32_t)w0, b0);
+    code = (code << 8) | encode4((uint32_t)(w0 >> 32), b1);
+    code = (code << 8) | encode4((uint32_t)w1, b2);
+    uint32_t last = encode4((uint32_t)(w1 >> 32), b3);             // one real byte
+    code = (code << 2) | (last >> 6);
+    Enc13 e;
+    e.code = code;
+    e.valid = ((b0 | b1 | b2 | (b3 & 0x00000001u)) == 0);
+    return e;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MPHF evaluation against the device layout
+// ---------------------------------------------------------------------------------------------
+struct MphfDev {
+    const BvRec* recs;   // W records
+    uint64_t D;          // hash domain
+    uint64_t seed;
+    uint64_t nrecs;      // W
+    FastMod fm;
+};
+
+__device__ __forceinline__ uint64_t mphf_from_hash(const MphfDev& m, uint64_t a, uint64_t b, uint64_t c) {
+    const uint64_t n0 = fastmod(a, m.fm);
+    const uint64_t n1 = m.D + fastmod(b, m.fm);
+    const uint64_t n2 = 2 * m.D + fastmod(c, m.fm);
+    const BvRec r0 = m.recs[n0 >> 5];
+    const BvRec r1 = m.recs[n1 >> 5];
+    const BvRec r2 = m.recs[n2 >> 5];
+    const uint32_t s0 = (uint32_t)(n0 & 31) * 2, s1 = (uint32_t)(n1 & 31) * 2, s2 = (uint32_t)(n2 & 31) * 2;
+    const uint32_t v = (uint32_t)((r0.word >> s0) & 3) + (uint32_t)((r1.word >> s1) & 3) + (uint32_t)((r2.word >> s2) & 3);
+    const uint32_t hidx = v - 3u * ((v * 11u) >> 5);               // v in 0..9 -> v % 3
+    const uint64_t w = hidx == 0 ? r0.word : (hidx == 1 ? r1.word : r2.word);
+    const uint32_t p = hidx == 0 ? r0.prefix : (hidx == 1 ? r1.prefix : r2.prefix);
+    const uint32_t sh = hidx == 0 ? s0 : (hidx == 1 ? s1 : s2);
+    return (uint64_t)p + popc_pairs(w & ((1ULL << sh) - 1));
+}
+
+}  // namespace aix

@@ -1,0 +1,56 @@
+// aix_internal.hpp — host-side view of an index resident in HBM + kernel launcher prototypes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "aix_device.hpp"
+
+namespace aix {
+
+// what kernels receive by value
+struct IndexDev {
+    MphfDev m;
+    const KeyRec* keys;       // 23-mer: n records {code, tf}
+    uint64_t n;               // 23-mer: number of keys; 13-mer: 4^13
+    const uint64_t* tf13_code;  // 13-mer: tf in 2-bit-code order (u64[4^13])
+    const uint64_t* tf13_mphf;  // 13-mer: tf in mphf order (the file's order)
+    uint32_t canonical_only;  // 23-mer: every stored code <= its reverse complement
+    uint32_t k;
+};
+
+enum LookupMode { MODE_TF = 0, MODE_HASH = 1, MODE_KIDSTRAND = 2, MODE_BOTH = 3, MODE_TOTAL = 4 };
+
+struct LookupOut {
+    uint32_t* tf;       // MODE_TF
+    uint64_t* u64a;     // HASH: hash; KIDSTRAND: kid; BOTH: fwd; TOTAL: sum
+    uint64_t* u64b;     // BOTH: rc
+    uint8_t* strand;    // KIDSTRAND
+};
+
+// launchers (aix_kernels.hip). All asynchronous on `stream`; return hipGetLastError().
+hipError_t launch_lookup23_ascii(const IndexDev& ix, const uint8_t* q, uint64_t N, int mode, LookupOut out, hipStream_t s);
+hipError_t launch_lookup23_codes(const IndexDev& ix, const uint64_t* codes, uint64_t N, uint32_t* out, hipStream_t s);
+hipError_t launch_lookup23_ragged(const IndexDev& ix, const uint8_t* bytes, const uint64_t* offs, uint64_t N, uint32_t* out, hipStream_t s);
+hipError_t launch_lookup13_ascii(const IndexDev& ix, const uint8_t* q, uint64_t N, int mode, LookupOut out, hipStream_t s);
+hipError_t launch_lookup13_ragged(const IndexDev& ix, const uint8_t* bytes, const uint64_t* offs, uint64_t N, uint32_t* out, hipStream_t s);
+hipError_t launch_coverage(const IndexDev& ix, const uint8_t* seqs, const uint64_t* offs, uint64_t M, uint64_t total_bytes,
+                           uint32_t cutoff, uint32_t* out, const uint64_t* out_offs, hipStream_t s);
+
+// index construction helpers
+hipError_t launch_build_keyrecs(const uint64_t* checker, const uint32_t* tf, uint64_t n, KeyRec* recs, uint32_t* noncanon_count, hipStream_t s);
+hipError_t launch_perm13(const MphfDev& m, uint32_t* perm /* [4^13]: code -> mphf index */, hipStream_t s);
+hipError_t launch_tf13_to_code_order(const uint32_t* perm, const uint64_t* tf_mphf, uint64_t* tf_code, hipStream_t s);
+hipError_t launch_extract_tf(const KeyRec* recs, uint64_t n, uint32_t* tf, uint64_t* checker, hipStream_t s);
+
+// counting
+hipError_t launch_count13_plain(const uint8_t* buf, uint64_t len, unsigned long long* table_code /* [4^13] */, hipStream_t s);
+hipError_t launch_scatter13_to_mphf(const uint32_t* perm, const unsigned long long* table_code, uint64_t* out_mphf, hipStream_t s);
+hipError_t launch_count23_fixed(const IndexDev& ix, const uint8_t* buf, uint64_t len, int canon_mode, uint32_t* tf_out, hipStream_t s);
+
+// synthetic generators
+hipError_t launch_synth_genome(uint64_t seed, uint64_t length, uint8_t* out, hipStream_t s);
+hipError_t launch_synth_kmers(uint64_t seed, uint64_t first, uint64_t N, int k, uint8_t* out, hipStream_t s);
+hipError_t launch_synth_reads(uint64_t seed, const uint8_t* genome, uint64_t genome_len, uint64_t first_read, uint64_t n_reads,
+                              uint32_t read_len, int rc_half, uint32_t n_rate_ppm, uint8_t* out, hipStream_t s);
+
+}  // namespace aix

@@ -1,0 +1,564 @@
+// aix_kernels.hip — hand-written HIP kernels for gfx950 (MI355X): batch MPHF lookups (23-/13-mer),
+// per-position coverage, k-mer counting, index re-layout, synthetic generators.
+//
+// All kernels are HBM/latency-bound integer work (no MFMA): one query / window per lane, three
+// independent 16-byte MPHF record reads + one 16-byte key record read per probe, grid-stride
+// launches of >= 8 workgroups per CU so that ~2k probes per CU are in flight.
+#include "aix_internal.hpp"
+
+namespace aix {
+
+static constexpr int kBlock = 256;
+static inline unsigned grid_for(uint64_t work, unsigned per_block = kBlock) {
+    uint64_t b = (work + per_block - 1) / per_block;
+    const uint64_t cap = 256ull * 32ull;          // 256 CUs x 32 resident-ish blocks, grid-stride beyond
+    if (b > cap) b = cap;
+    if (b == 0) b = 1;
+    return (unsigned)b;
+}
+
+// ---------------------------------------------------------------------------------------------
+// unaligned window loads. Every dword that is read contains at least one byte of the window, so a
+// window that lies inside the caller's buffer can never fault, whatever the buffer's alignment.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load23(const uint8_t* p, uint64_t& w0, uint64_t& w1, uint64_t& w2) {
+    const uintptr_t a = (uintptr_t)p;
+    const uint32_t o = (uint32_t)(a & 3);
+    const uint32_t* q = (const uint32_t*)(a - o);
+    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4], d5 = q[5];
+    const uint32_t d6 = (o >= 2) ? q[6] : 0u;        // bytes 20..22 reach dword 6 only when o >= 2
+    const uint32_t sh = o * 8;
+    const uint32_t e0 = __funnelshift_r(d0, d1, sh), e1 = __funnelshift_r(d1, d2, sh);
+    const uint32_t e2 = __funnelshift_r(d2, d3, sh), e3 = __funnelshift_r(d3, d4, sh);
+    const uint32_t e4 = __funnelshift_r(d4, d5, sh), e5 = __funnelshift_r(d5, d6, sh) & 0x00FFFFFFu;
+    w0 = e0 | ((uint64_t)e1 << 32);
+    w1 = e2 | ((uint64_t)e3 << 32);
+    w2 = e4 | ((uint64_t)e5 << 32);
+}
+__device__ __forceinline__ void load13(const uint8_t* p, uint64_t& w0, uint64_t& w1) {
+    const uintptr_t a = (uintptr_t)p;
+    const uint32_t o = (uint32_t)(a & 3);
+    const uint32_t* q = (const uint32_t*)(a - o);
+    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3];   // byte 12 lies in dword 3 for every o
+    const uint32_t sh = o * 8;
+    const uint32_t e0 = __funnelshift_r(d0, d1, sh), e1 = __funnelshift_r(d1, d2, sh);
+    const uint32_t e2 = __funnelshift_r(d2, d3, sh), e3 = __funnelshift_r(d3, 0u, sh) & 0x000000FFu;
+    w0 = e0 | ((uint64_t)e1 << 32);
+    w1 = e2 | ((uint64_t)e3 << 32);
+}
+
+// ---------------------------------------------------------------------------------------------
+// probes
+// ---------------------------------------------------------------------------------------------
+struct Probe {
+    uint64_t slot;
+    uint32_t tf;
+    bool found;
+};
+// hash the 23 ASCII bytes in (w0,w1,w2), evaluate the MPHF, verify against the stored code
+__device__ __forceinline__ Probe probe23(const IndexDev& ix, uint64_t w0, uint64_t w1, uint64_t w2, uint64_t code) {
+    uint64_t a, b, c;
+    jenkins23(w0, w1, w2, ix.m.seed, a, b, c);
+    Probe r;
+    r.slot = mphf_from_hash(ix.m, a, b, c);
+    r.found = false;
+    r.tf = 0;
+    if (r.slot < ix.n) {                           // python_wrapper.cpp:613 `h1 >= n ||`
+        const KeyRec k = ix.keys[r.slot];
+        if (k.code == code) { r.found = true; r.tf = k.tf; }
+    }
+    return r;
+}
+// same, but the forward hash (a,b,c) was computed elsewhere (ragged lengths)
+__device__ __forceinline__ Probe probe23_hashed(const IndexDev& ix, uint64_t a, uint64_t b, uint64_t c, uint64_t code) {
+    Probe r;
+    r.slot = mphf_from_hash(ix.m, a, b, c);
+    r.found = false;
+    r.tf = 0;
+    if (r.slot < ix.n) {
+        const KeyRec k = ix.keys[r.slot];
+        if (k.code == code) { r.found = true; r.tf = k.tf; }
+    }
+    return r;
+}
+
+// Result of get_tf_value_23mer-style probing (python_wrapper.cpp:610-627): strand 0 absent, 1 fwd, 2 rc
+struct Q23 {
+    uint64_t slot;
+    uint32_t tf;
+    uint32_t strand;
+};
+template <bool CANON>
+__device__ __forceinline__ Q23 query23(const IndexDev& ix, uint64_t w0, uint64_t w1, uint64_t w2) {
+    const Enc23 e = encode23_words(w0, w1, w2);
+    const uint64_t r = revcomp(e.code, 23);
+    Q23 out;
+    out.slot = 0; out.tf = 0; out.strand = 0;
+    if (CANON && e.valid) {
+        // every stored code is canonical: only the canonical strand of the query can match
+        if (e.code <= r) {
+            const Probe p = probe23(ix, w0, w1, w2, e.code);
+            if (p.found) { out.slot = p.slot; out.tf = p.tf; out.strand = 1; }
+        } else {
+            uint64_t r0, r1, r2;
+            ascii23_of_rc(e.code, r0, r1, r2);
+            const Probe p = probe23(ix, r0, r1, r2, r);
+            if (p.found) { out.slot = p.slot; out.tf = p.tf; out.strand = 2; }
+        }
+        return out;
+    }
+    const Probe f = probe23(ix, w0, w1, w2, e.code);           // raw bytes hashed, sanitised code compared
+    if (f.found) { out.slot = f.slot; out.tf = f.tf; out.strand = 1; return out; }
+    uint64_t r0, r1, r2;
+    ascii23_of_rc(e.code, r0, r1, r2);                          // decode(reverseDNA(u)), :615-616
+    const Probe g = probe23(ix, r0, r1, r2, r);
+    if (g.found) { out.slot = g.slot; out.tf = g.tf; out.strand = 2; }
+    return out;
+}
+
+// get_tf_both_directions_23mer (python_wrapper.cpp:1259-1275): Q1(q) and Q1(decode(rc(q)))
+template <bool CANON>
+__device__ __forceinline__ void both23(const IndexDev& ix, uint64_t w0, uint64_t w1, uint64_t w2, uint32_t& fwd, uint32_t& rc) {
+    const Enc23 e = encode23_words(w0, w1, w2);
+    const uint64_t r = revcomp(e.code, 23);
+    if (CANON && e.valid) {
+        const Q23 q = query23<true>(ix, w0, w1, w2);
+        fwd = q.tf; rc = q.tf;
+        return;
+    }
+    uint64_t r0, r1, r2;
+    ascii23_of_rc(e.code, r0, r1, r2);
+    const Probe F = probe23(ix, w0, w1, w2, e.code);
+    const Probe R = probe23(ix, r0, r1, r2, r);
+    Probe S = F;
+    if (!e.valid) {                                             // second call's fallback decodes the sanitised code
+        uint64_t s0, s1, s2;
+        ascii23_of_rc(r, s0, s1, s2);
+        S = probe23(ix, s0, s1, s2, e.code);
+    }
+    fwd = F.found ? F.tf : (R.found ? R.tf : 0u);
+    rc = R.found ? R.tf : (S.found ? S.tf : 0u);
+}
+
+template <int MODE, bool CANON>
+__global__ void __launch_bounds__(kBlock) k_lookup23_ascii(const IndexDev ix, const uint8_t* __restrict__ q, uint64_t N, LookupOut out) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += stride) {
+        uint64_t w0, w1, w2;
+        load23(q + 23 * i, w0, w1, w2);
+        if (MODE == MODE_TF) {
+            out.tf[i] = query23<CANON>(ix, w0, w1, w2).tf;
+        } else if (MODE == MODE_HASH) {
+            uint64_t a, b, c;
+            jenkins23(w0, w1, w2, ix.m.seed, a, b, c);
+            out.u64a[i] = mphf_from_hash(ix.m, a, b, c);
+        } else if (MODE == MODE_KIDSTRAND) {
+            const Q23 r = query23<CANON>(ix, w0, w1, w2);
+            if (out.u64a) out.u64a[i] = r.slot;                 // get_kid_by_kmer: 0 when absent (:700-716)
+            if (out.strand) out.strand[i] = (uint8_t)r.strand;
+        } else {
+            uint32_t f, r;
+            both23<CANON>(ix, w0, w1, w2, f, r);
+            if (MODE == MODE_TOTAL) {
+                out.u64a[i] = (uint64_t)f + (uint64_t)r;
+            } else {
+                if (out.u64a) out.u64a[i] = f;
+                if (out.u64b) out.u64b[i] = r;
+            }
+        }
+    }
+}
+
+template <bool CANON>
+__global__ void __launch_bounds__(kBlock) k_lookup23_codes(const IndexDev ix, const uint64_t* __restrict__ codes, uint64_t N, uint32_t* __restrict__ out) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += stride) {
+        const uint64_t u = codes[i] & ((1ULL << 46) - 1);
+        const uint64_t r = revcomp(u, 23);
+        uint64_t w0, w1, w2;
+        uint32_t tf = 0;
+        if (CANON) {
+            const uint64_t key = u <= r ? u : r;
+            ascii23_of_rc(u <= r ? r : u, w0, w1, w2);           // string of `key`
+            const Probe p = probe23(ix, w0, w1, w2, key);
+            tf = p.found ? p.tf : 0u;
+        } else {
+            ascii23_of_rc(r, w0, w1, w2);
+            const Probe f = probe23(ix, w0, w1, w2, u);
+            if (f.found) tf = f.tf;
+            else {
+                ascii23_of_rc(u, w0, w1, w2);
+                const Probe g = probe23(ix, w0, w1, w2, r);
+                tf = g.found ? g.tf : 0u;
+            }
+        }
+        out[i] = tf;
+    }
+}
+
+// variable-length queries: the reference hashes ALL bytes of the std::string but encodes the first 23
+__global__ void __launch_bounds__(kBlock) k_lookup23_ragged(const IndexDev ix, const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offs,
+                                                           uint64_t N, uint32_t* __restrict__ out) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += stride) {
+        const uint64_t lo = offs[i], len = offs[i + 1] - lo;
+        uint32_t tf = 0;
+        if (len >= 23) {
+            uint64_t w0, w1, w2;
+            load23(bytes + lo, w0, w1, w2);
+            if (len == 23) {
+                tf = query23<false>(ix, w0, w1, w2).tf;
+            } else {
+                const Enc23 e = encode23_words(w0, w1, w2);
+                uint64_t a, b, c;
+                jenkins_bytes(bytes + lo, len, ix.m.seed, a, b, c);
+                const Probe f = probe23_hashed(ix, a, b, c, e.code);
+                if (f.found) tf = f.tf;
+                else {
+                    uint64_t r0, r1, r2;
+                    ascii23_of_rc(e.code, r0, r1, r2);
+                    const Probe g = probe23(ix, r0, r1, r2, revcomp(e.code, 23));
+                    tf = g.found ? g.tf : 0u;
+                }
+            }
+        }
+        out[i] = tf;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 13-mer mode: the MPHF over all 4^13 13-mers is a bijection code -> slot, so the table is kept in
+// 2-bit-code order in HBM (tf13_code) and a valid query is one 8-byte read. Queries with bytes
+// outside ACGT take the reference's raw-bytes MPHF path against the mphf-ordered copy.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t tf13_raw(const IndexDev& ix, uint64_t w0, uint64_t w1) {
+    uint64_t a, b, c;
+    jenkins13(w0, w1, ix.m.seed, a, b, c);
+    const uint64_t h = mphf_from_hash(ix.m, a, b, c);
+    return h < 67108864ull ? ix.tf13_mphf[h] : 0ull;            // reference indexes unguarded (:534); OOB -> 0
+}
+// get_reverse_complement_13mer (python_wrapper.cpp:505-517) on raw bytes: reverse; A<->T, C<->G; others kept
+__device__ __forceinline__ void rc13_raw(uint64_t w0, uint64_t w1, uint64_t& r0, uint64_t& r1) {
+    r0 = 0; r1 = 0;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) {
+        const int j = 12 - i;
+        uint32_t ch = (uint32_t)((j < 8 ? (w0 >> (8 * j)) : (w1 >> (8 * (j - 8)))) & 0xff);
+        ch = ch == 'A' ? 'T' : ch == 'T' ? 'A' : ch == 'G' ? 'C' : ch == 'C' ? 'G' : ch;
+        if (i < 8) r0 |= (uint64_t)ch << (8 * i);
+        else r1 |= (uint64_t)ch << (8 * (i - 8));
+    }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(kBlock) k_lookup13_ascii(const IndexDev ix, const uint8_t* __restrict__ q, uint64_t N, LookupOut out) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += stride) {
+        uint64_t w0, w1;
+        load13(q + 13 * i, w0, w1);
+        const Enc13 e = encode13_words(w0, w1);
+        if (MODE == MODE_TF) {                                  // get_tf_values_13mer :938-980: strict, u32 truncation
+            out.tf[i] = e.valid ? (uint32_t)ix.tf13_code[e.code] : 0u;
+        } else {
+            uint64_t f, r;
+            if (e.valid) {
+                f = ix.tf13_code[e.code];
+                r = ix.tf13_code[(uint32_t)revcomp(e.code, 13)];
+            } else {                                            // :522-543 has no validation: raw bytes are hashed
+                uint64_t r0, r1;
+                rc13_raw(w0, w1, r0, r1);
+                f = tf13_raw(ix, w0, w1);
+                r = tf13_raw(ix, r0, r1);
+            }
+            if (MODE == MODE_TOTAL) out.u64a[i] = f + r;
+            else {
+                if (out.u64a) out.u64a[i] = f;
+                if (out.u64b) out.u64b[i] = r;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_lookup13_ragged(const IndexDev ix, const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offs,
+                                                           uint64_t N, uint32_t* __restrict__ out) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += stride) {
+        const uint64_t lo = offs[i], len = offs[i + 1] - lo;
+        uint32_t tf = 0;
+        if (len == 13) {                                        // is_13mer(): length check first (:943)
+            uint64_t w0, w1;
+            load13(bytes + lo, w0, w1);
+            const Enc13 e = encode13_words(w0, w1);
+            if (e.valid) tf = (uint32_t)ix.tf13_code[e.code];
+        }
+        out[i] = tf;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// coverage: one lane per byte position of the concatenated sequences (aindex.py:314-322)
+// ---------------------------------------------------------------------------------------------
+template <bool CANON>
+__global__ void __launch_bounds__(kBlock) k_coverage(const IndexDev ix, const uint8_t* __restrict__ seqs, const uint64_t* __restrict__ offs, uint64_t M,
+                                                    uint64_t total, uint32_t cutoff, uint32_t* __restrict__ out, const uint64_t* __restrict__ out_offs) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    const uint32_t k = ix.k;
+    for (uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x; p < total; p += stride) {
+        // sequence containing byte p: largest s with offs[s] <= p
+        uint64_t lo = 0, hi = M;                                // invariant offs[lo] <= p < offs[hi]
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (offs[mid] <= p) lo = mid; else hi = mid;
+        }
+        const uint64_t s = lo, begin = offs[s], end = offs[s + 1];
+        if (p < begin || p + k > end) continue;                 // p < begin: gaps between sequences are allowed
+        uint32_t tf;
+        if (k == 23) {
+            uint64_t w0, w1, w2;
+            load23(seqs + p, w0, w1, w2);
+            tf = query23<CANON>(ix, w0, w1, w2).tf;
+        } else {
+            uint64_t w0, w1;
+            load13(seqs + p, w0, w1);
+            const Enc13 e = encode13_words(w0, w1);
+            tf = e.valid ? (uint32_t)ix.tf13_code[e.code] : 0u;
+        }
+        out[out_offs[s] + (p - begin)] = tf >= cutoff ? tf : 0u;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// index re-layout
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) k_build_keyrecs(const uint64_t* __restrict__ checker, const uint32_t* __restrict__ tf, uint64_t n, KeyRec* __restrict__ recs,
+                                                         uint32_t* __restrict__ noncanon) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    uint32_t bad = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        KeyRec r;
+        r.code = checker[i];
+        r.tf = tf[i];
+        r.pad = 0;
+        recs[i] = r;
+        bad |= (r.code > revcomp(r.code & ((1ULL << 46) - 1), 23)) || (r.code >> 46);
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicAdd(noncanon, 1u);
+}
+__global__ void __launch_bounds__(kBlock) k_extract(const KeyRec* __restrict__ recs, uint64_t n, uint32_t* __restrict__ tf, uint64_t* __restrict__ checker) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const KeyRec r = recs[i];
+        if (tf) tf[i] = r.tf;
+        if (checker) checker[i] = r.code;
+    }
+}
+// perm[code] = mphf13(ASCII(code)) for all 4^13 codes
+__global__ void __launch_bounds__(kBlock) k_perm13(const MphfDev m, uint32_t* __restrict__ perm) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t code = (uint64_t)blockIdx.x * kBlock + threadIdx.x; code < 67108864ull; code += stride) {
+        uint64_t w0, w1, a, b, c;
+        ascii13_of_rc((uint32_t)revcomp(code, 13), w0, w1);
+        jenkins13(w0, w1, m.seed, a, b, c);
+        perm[code] = (uint32_t)mphf_from_hash(m, a, b, c);
+    }
+}
+__global__ void __launch_bounds__(kBlock) k_tf13_to_code(const uint32_t* __restrict__ perm, const uint64_t* __restrict__ tf_mphf, uint64_t* __restrict__ tf_code) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t code = (uint64_t)blockIdx.x * kBlock + threadIdx.x; code < 67108864ull; code += stride) {
+        const uint32_t h = perm[code];
+        tf_code[code] = h < 67108864u ? tf_mphf[h] : 0ull;
+    }
+}
+__global__ void __launch_bounds__(kBlock) k_scatter13(const uint32_t* __restrict__ perm, const unsigned long long* __restrict__ table_code, uint64_t* __restrict__ out_mphf) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t code = (uint64_t)blockIdx.x * kBlock + threadIdx.x; code < 67108864ull; code += stride) {
+        const uint32_t h = perm[code];
+        if (h < 67108864u) out_mphf[h] = table_code[code];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// counting (PLAIN form: any byte that is not a base breaks the window; '\n' separates sequences)
+// ---------------------------------------------------------------------------------------------
+// count_kmers13.cpp:113-161: upper-case, ACGT only, forward strand; one lane per window start
+__global__ void __launch_bounds__(kBlock) k_count13(const uint8_t* __restrict__ buf, uint64_t len, unsigned long long* __restrict__ table) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    if (len < 13) return;
+    const uint64_t nwin = len - 12;
+    for (uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x; p < nwin; p += stride) {
+        uint64_t w0, w1;
+        load13(buf + p, w0, w1);
+        w0 &= 0xDFDFDFDFDFDFDFDFULL;                            // toupper for letters; nothing else maps onto ACGT
+        w1 &= 0xDFDFDFDFDFDFDFDFULL;
+        const Enc13 e = encode13_words(w0, w1);
+        if (e.valid) atomicAdd(&table[e.code], 1ULL);
+    }
+}
+
+// bytes equal to 'U' -> 'T' (after upper-casing), count_kmers.cpp:71-88
+__device__ __forceinline__ uint64_t u_to_t(uint64_t x) {
+    const uint64_t z = x ^ 0x5555555555555555ULL;
+    const uint64_t nz = (((z & 0x7F7F7F7F7F7F7F7FULL) + 0x7F7F7F7F7F7F7F7FULL) | z) & 0x8080808080808080ULL;
+    return x ^ ((~nz & 0x8080808080808080ULL) >> 7);
+}
+__global__ void __launch_bounds__(kBlock) k_count23_fixed(const IndexDev ix, const uint8_t* __restrict__ buf, uint64_t len, int canon_mode, uint32_t* __restrict__ tf_out) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    if (len < 23) return;
+    const uint64_t nwin = len - 22;
+    for (uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x; p < nwin; p += stride) {
+        uint64_t w0, w1, w2;
+        load23(buf + p, w0, w1, w2);
+        w0 = u_to_t(w0 & 0xDFDFDFDFDFDFDFDFULL);
+        w1 = u_to_t(w1 & 0xDFDFDFDFDFDFDFDFULL);
+        w2 = u_to_t(w2 & 0x00DFDFDFDFDFDFDFULL);
+        const Enc23 e = encode23_words(w0, w1, w2);
+        if (!e.valid) continue;
+        uint64_t key = e.code;
+        if (canon_mode == 1) { const uint64_t x = revcomp_refx86(e.code, 23); key = e.code < x ? e.code : x; }
+        else if (canon_mode == 2) { const uint64_t x = revcomp(e.code, 23); key = e.code < x ? e.code : x; }
+        uint64_t s0, s1, s2;
+        ascii23_of_rc(revcomp(key, 23), s0, s1, s2);
+        const Probe pr = probe23(ix, s0, s1, s2, key);
+        if (pr.found) atomicAdd(&tf_out[pr.slot], 1u);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// synthetic inputs (bit-identical to aindex_amd/synth.py)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t sm64(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+__global__ void __launch_bounds__(kBlock) k_synth_genome(uint64_t seed, uint64_t length, uint8_t* __restrict__ out) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t j = (uint64_t)blockIdx.x * kBlock + threadIdx.x; j < length; j += stride) {
+        const uint64_t v = sm64(seed, j >> 5);
+        out[j] = (uint8_t)(AIX_LUT_ACGT >> (8 * ((v >> (2 * (j & 31))) & 3)));
+    }
+}
+__global__ void __launch_bounds__(kBlock) k_synth_kmers(uint64_t seed, uint64_t first, uint64_t N, int k, uint8_t* __restrict__ out) {
+    const uint64_t total = N * (uint64_t)k, stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += stride) {
+        const uint64_t i = t / (uint64_t)k, j = t - i * (uint64_t)k;
+        const uint64_t v = sm64(seed, first + i);
+        out[t] = (uint8_t)(AIX_LUT_ACGT >> (8 * ((v >> (2 * (k - 1 - (int)j))) & 3)));
+    }
+}
+__global__ void __launch_bounds__(kBlock) k_synth_reads(uint64_t seed, const uint8_t* __restrict__ genome, uint64_t glen, uint64_t first_read, uint64_t n_reads,
+                                                       uint32_t read_len, int rc_half, uint32_t n_ppm, uint8_t* __restrict__ out) {
+    const uint64_t rec = (uint64_t)read_len + 1, total = n_reads * rec, stride = (uint64_t)gridDim.x * kBlock;
+    const uint64_t span = glen - read_len + 1;
+    for (uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += stride) {
+        const uint64_t ri = t / rec, j = t - ri * rec;
+        if (j == read_len) { out[t] = '\n'; continue; }
+        const uint64_t r = first_read + ri;
+        const uint64_t v = sm64(seed, 2 * r);
+        const uint64_t start = ((v >> 32) * span) >> 32;
+        uint8_t ch;
+        if (rc_half && (sm64(seed, 2 * r + 1) & 1)) {
+            const uint8_t g = genome[start + (read_len - 1 - j)];
+            ch = g == 'A' ? 'T' : g == 'C' ? 'G' : g == 'G' ? 'C' : g == 'T' ? 'A' : g;
+        } else {
+            ch = genome[start + j];
+        }
+        if (n_ppm) {
+            const uint64_t h = sm64(seed ^ 0x5851F42D4C957F2DULL, r * read_len + j);
+            if ((((h >> 32) * 1000000ULL) >> 32) < n_ppm) ch = 'N';
+        }
+        out[t] = ch;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+#define AIX_LAUNCH(kern, work, stream, ...)                                          \
+    do {                                                                             \
+        hipLaunchKernelGGL(kern, dim3(grid_for(work)), dim3(kBlock), 0, stream, __VA_ARGS__); \
+        return hipGetLastError();                                                    \
+    } while (0)
+
+template <bool CANON>
+static hipError_t lookup23_ascii_mode(const IndexDev& ix, const uint8_t* q, uint64_t N, int mode, LookupOut out, hipStream_t s) {
+    switch (mode) {
+        case MODE_TF: AIX_LAUNCH((k_lookup23_ascii<MODE_TF, CANON>), N, s, ix, q, N, out);
+        case MODE_HASH: AIX_LAUNCH((k_lookup23_ascii<MODE_HASH, CANON>), N, s, ix, q, N, out);
+        case MODE_KIDSTRAND: AIX_LAUNCH((k_lookup23_ascii<MODE_KIDSTRAND, CANON>), N, s, ix, q, N, out);
+        case MODE_BOTH: AIX_LAUNCH((k_lookup23_ascii<MODE_BOTH, CANON>), N, s, ix, q, N, out);
+        case MODE_TOTAL: AIX_LAUNCH((k_lookup23_ascii<MODE_TOTAL, CANON>), N, s, ix, q, N, out);
+    }
+    return hipErrorInvalidValue;
+}
+hipError_t launch_lookup23_ascii(const IndexDev& ix, const uint8_t* q, uint64_t N, int mode, LookupOut out, hipStream_t s) {
+    if (N == 0) return hipSuccess;
+    return ix.canonical_only ? lookup23_ascii_mode<true>(ix, q, N, mode, out, s) : lookup23_ascii_mode<false>(ix, q, N, mode, out, s);
+}
+hipError_t launch_lookup23_codes(const IndexDev& ix, const uint64_t* codes, uint64_t N, uint32_t* out, hipStream_t s) {
+    if (N == 0) return hipSuccess;
+    if (ix.canonical_only) AIX_LAUNCH(k_lookup23_codes<true>, N, s, ix, codes, N, out);
+    AIX_LAUNCH(k_lookup23_codes<false>, N, s, ix, codes, N, out);
+}
+hipError_t launch_lookup23_ragged(const IndexDev& ix, const uint8_t* bytes, const uint64_t* offs, uint64_t N, uint32_t* out, hipStream_t s) {
+    if (N == 0) return hipSuccess;
+    AIX_LAUNCH(k_lookup23_ragged, N, s, ix, bytes, offs, N, out);
+}
+hipError_t launch_lookup13_ascii(const IndexDev& ix, const uint8_t* q, uint64_t N, int mode, LookupOut out, hipStream_t s) {
+    if (N == 0) return hipSuccess;
+    switch (mode) {
+        case MODE_TF: AIX_LAUNCH(k_lookup13_ascii<MODE_TF>, N, s, ix, q, N, out);
+        case MODE_BOTH: AIX_LAUNCH(k_lookup13_ascii<MODE_BOTH>, N, s, ix, q, N, out);
+        case MODE_TOTAL: AIX_LAUNCH(k_lookup13_ascii<MODE_TOTAL>, N, s, ix, q, N, out);
+    }
+    return hipErrorInvalidValue;
+}
+hipError_t launch_lookup13_ragged(const IndexDev& ix, const uint8_t* bytes, const uint64_t* offs, uint64_t N, uint32_t* out, hipStream_t s) {
+    if (N == 0) return hipSuccess;
+    AIX_LAUNCH(k_lookup13_ragged, N, s, ix, bytes, offs, N, out);
+}
+hipError_t launch_coverage(const IndexDev& ix, const uint8_t* seqs, const uint64_t* offs, uint64_t M, uint64_t total, uint32_t cutoff, uint32_t* out,
+                           const uint64_t* out_offs, hipStream_t s) {
+    if (M == 0 || total == 0) return hipSuccess;
+    if (ix.k == 23 && ix.canonical_only) AIX_LAUNCH(k_coverage<true>, total, s, ix, seqs, offs, M, total, cutoff, out, out_offs);
+    AIX_LAUNCH(k_coverage<false>, total, s, ix, seqs, offs, M, total, cutoff, out, out_offs);
+}
+hipError_t launch_build_keyrecs(const uint64_t* checker, const uint32_t* tf, uint64_t n, KeyRec* recs, uint32_t* noncanon, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    AIX_LAUNCH(k_build_keyrecs, n, s, checker, tf, n, recs, noncanon);
+}
+hipError_t launch_extract_tf(const KeyRec* recs, uint64_t n, uint32_t* tf, uint64_t* checker, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    AIX_LAUNCH(k_extract, n, s, recs, n, tf, checker);
+}
+hipError_t launch_perm13(const MphfDev& m, uint32_t* perm, hipStream_t s) { AIX_LAUNCH(k_perm13, 67108864ull, s, m, perm); }
+hipError_t launch_tf13_to_code_order(const uint32_t* perm, const uint64_t* tf_mphf, uint64_t* tf_code, hipStream_t s) {
+    AIX_LAUNCH(k_tf13_to_code, 67108864ull, s, perm, tf_mphf, tf_code);
+}
+hipError_t launch_count13_plain(const uint8_t* buf, uint64_t len, unsigned long long* table, hipStream_t s) {
+    if (len < 13) return hipSuccess;
+    AIX_LAUNCH(k_count13, len - 12, s, buf, len, table);
+}
+hipError_t launch_scatter13_to_mphf(const uint32_t* perm, const unsigned long long* table, uint64_t* out, hipStream_t s) {
+    AIX_LAUNCH(k_scatter13, 67108864ull, s, perm, table, out);
+}
+hipError_t launch_count23_fixed(const IndexDev& ix, const uint8_t* buf, uint64_t len, int canon_mode, uint32_t* tf_out, hipStream_t s) {
+    if (len < 23 || ix.n == 0) return hipSuccess;
+    AIX_LAUNCH(k_count23_fixed, len - 22, s, ix, buf, len, canon_mode, tf_out);
+}
+hipError_t launch_synth_genome(uint64_t seed, uint64_t length, uint8_t* out, hipStream_t s) {
+    if (length == 0) return hipSuccess;
+    AIX_LAUNCH(k_synth_genome, length, s, seed, length, out);
+}
+hipError_t launch_synth_kmers(uint64_t seed, uint64_t first, uint64_t N, int k, uint8_t* out, hipStream_t s) {
+    if (N == 0) return hipSuccess;
+    AIX_LAUNCH(k_synth_kmers, N * (uint64_t)k, s, seed, first, N, k, out);
+}
+hipError_t launch_synth_reads(uint64_t seed, const uint8_t* genome, uint64_t glen, uint64_t first_read, uint64_t n_reads, uint32_t read_len, int rc_half,
+                              uint32_t n_ppm, uint8_t* out, hipStream_t s) {
+    if (n_reads == 0) return hipSuccess;
+    AIX_LAUNCH(k_synth_reads, n_reads * ((uint64_t)read_len + 1), s, seed, genome, glen, first_read, n_reads, read_len, rc_half, n_ppm, out);
+}
+
+}  // namespace aix

@@ -1,0 +1,197 @@
+/* include/aindex_hip.h — C ABI of libaindex_hip.so (MI355X / gfx950).
+ *
+ * This is the drop-in boundary for the k-mer count / perfect-hash lookup path of ad3002/aindex.
+ * Every entry point names the reference interface it replaces (file:line under /root/reference).
+ * Plain pointers and sizes only; no C++/torch types. All functions return an int status
+ * (AIX_OK = 0, negative = error, see aix_strerror) and never abort the process — the reference's
+ * std::terminate()/exit(10|12) paths (python_wrapper.cpp:265,413,1118; hash.cpp:37,129,153) become
+ * error codes. Queries are thread-safe per handle. The library fails loudly (AIX_ERR_HIP) when no
+ * HIP device is usable: there is NO CPU fallback behind this ABI.
+ *
+ * Naming: `*_dev` entry points take DEVICE pointers and a hipStream_t (passed as void*) and are
+ * asynchronous on that stream; the un-suffixed twins take HOST pointers, stage through HBM and
+ * return when the result is in the caller's buffer.
+ */
+#ifndef AINDEX_HIP_H
+#define AINDEX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AIX_OK               0
+#define AIX_ERR_ARG         -1   /* bad argument / NULL handle                                  */
+#define AIX_ERR_IO          -2   /* file missing or short (reference: std::terminate / exit(10)) */
+#define AIX_ERR_FORMAT      -3   /* malformed .pf / size mismatch                                */
+#define AIX_ERR_NOMEM       -4
+#define AIX_ERR_HIP         -5   /* HIP runtime error or no device                               */
+#define AIX_ERR_UNSUPPORTED -6   /* e.g. n >= 2^32 keys                                          */
+#define AIX_ERR_MODE        -7   /* 13-mer call on a 23-mer handle or vice versa                 */
+#define AIX_ERR_CONFLICT   -12   /* index scatter collision (reference: exit(12), hash.cpp:708)  */
+
+#define AIX_TOTAL_13MERS 67108864ull   /* 4^13, python_wrapper.cpp:141 */
+
+/* input formats of the counters (count_kmers13.cpp:187-206) */
+#define AIX_FMT_AUTO  -1
+#define AIX_FMT_PLAIN  0
+#define AIX_FMT_FASTA  1
+#define AIX_FMT_FASTQ  2
+
+/* canonical form used when counting 23-mers */
+#define AIX_CANON_NONE    0
+#define AIX_CANON_REF_X86 1   /* bit-exact with kmer_counter's defective rc, count_kmers.cpp:116-136 */
+#define AIX_CANON_TRUE_RC 2   /* true reverse complement (tests/analyze_kmers.py:19-80)              */
+
+typedef struct aix_index aix_index_t;   /* opaque: MPHF + tf/checker resident in HBM */
+
+typedef struct {
+    uint32_t k;               /* 23 or 13                                                     */
+    uint32_t device;          /* HIP device ordinal                                            */
+    uint64_t n;               /* keys: size(.kmers.bin)/8 (23) or 4^13 (13)                    */
+    uint64_t mphf_n;          /* n stored in the .pf                                           */
+    uint64_t hash_domain;     /* m_hash_domain, mphf.hpp:26                                    */
+    uint64_t seed;            /* jenkins64 seed                                                */
+    uint64_t bitpairs;        /* 3 * hash_domain                                               */
+    uint64_t device_bytes;    /* HBM held by this handle                                       */
+    uint32_t canonical_only;  /* 1 if every stored 23-mer code <= its reverse complement       */
+    uint32_t reserved;
+} aix_info_t;
+
+const char* aix_version(void);
+const char* aix_strerror(int status);
+int aix_device_count(int* count);                     /* AIX_ERR_HIP if the runtime is unusable  */
+
+/* ------------------------------------------------------------------------------------------
+ * Index lifecycle.
+ * replaces AindexWrapper::load / load_hash_file / load_from_prefix_23mer
+ *          (python_wrapper.cpp:228-258,1103-1132) + load_hash (hash.cpp:367-450)
+ *          AindexWrapper::load_13mer_index / load_from_prefix_13mer (python_wrapper.cpp:404-437,1162-1188)
+ * File layouts are the reference's: .pf = mphf::save (mphf.hpp:99-105), .kmers.bin = u64[n],
+ * .tf.bin = u32[n] (23-mer, compute_index.cpp:59-67) or u64[4^13] (13-mer, count_kmers13.cpp:358-388).
+ * ------------------------------------------------------------------------------------------ */
+int aix_index_open_23(const char* pf_path, const char* tf_bin_path, const char* kmers_bin_path,
+                      int device, aix_index_t** out);
+int aix_index_open_13(const char* pf_path, const char* tf_bin_path /* NULL: all-zero table */,
+                      int device, aix_index_t** out);
+/* same, from caller memory (host pointers) */
+int aix_index_create_23(const void* pf_bytes, uint64_t pf_len, const uint64_t* checker,
+                        const uint32_t* tf, uint64_t n, int device, aix_index_t** out);
+int aix_index_create_13(const void* pf_bytes, uint64_t pf_len, const uint64_t* tf /* 4^13 or NULL */,
+                        int device, aix_index_t** out);
+int aix_index_close(aix_index_t* h);                  /* ~AindexWrapper, python_wrapper.cpp:185-226 */
+int aix_index_info(const aix_index_t* h, aix_info_t* info);
+/* force the two-probe path even on an all-canonical index (A/B measurements) */
+int aix_index_set_canonical_fastpath(aix_index_t* h, int enabled);
+/* replace the tf table of a 13-mer handle (u64[4^13], mphf order, HOST pointer) */
+int aix_index_set_tf_13(aix_index_t* h, const uint64_t* tf);
+/* copy tf out (HOST pointer): 23 -> u32[n]; 13 -> u64[4^13] in mphf order
+ * replaces get_13mer_tf_array / get_tf_by_index_13mer (python_wrapper.cpp:983-998) */
+int aix_index_get_tf(const aix_index_t* h, void* out, uint64_t out_bytes);
+/* copy the checker (stored 2-bit codes, u64[n]) out; get_kmer_by_kid / get_kmer_info (:718-755) */
+int aix_index_get_checker(const aix_index_t* h, uint64_t* out, uint64_t n);
+
+/* ------------------------------------------------------------------------------------------
+ * Batch tf queries. `kmers` is N*k contiguous ASCII bytes (k = 23 or 13 per the handle).
+ * 23-mer handle: AindexWrapper::get_tf_values / get_tf_values_23mer / get_tf_value_23mer
+ *   (python_wrapper.cpp:610-627,653-664,1219-1228) bit-exact incl. the raw-bytes forward probe /
+ *   sanitised reverse probe asymmetry for non-ACGT bytes and forward-strand precedence.
+ * 13-mer handle: get_tf_values_13mer / get_tf_value_13mer (python_wrapper.cpp:482-503,938-980):
+ *   strict upper-case ACGT else 0, forward strand only, u64 -> u32 truncation.
+ * ------------------------------------------------------------------------------------------ */
+int aix_tf_batch_ascii(aix_index_t* h, const char* kmers, uint64_t N, uint32_t* out);
+int aix_tf_batch_ascii_dev(aix_index_t* h, const char* d_kmers, uint64_t N, uint32_t* d_out, void* stream);
+/* pre-encoded 2-bit codes (first base most significant; ACGT only), same answers as the ASCII call */
+int aix_tf_batch_codes(aix_index_t* h, const uint64_t* codes, uint64_t N, uint32_t* out);
+int aix_tf_batch_codes_dev(aix_index_t* h, const uint64_t* d_codes, uint64_t N, uint32_t* d_out, void* stream);
+/* variable-length queries: query i = bytes[offsets[i] .. offsets[i+1]). Mirrors what the reference
+ * does with a std::string of any length (hash of ALL bytes, code of the first k); lengths < k give 0
+ * (the reference reads past the string there). 23-mer handles only for len != k semantics; a 13-mer
+ * handle returns 0 unless len == 13 (python_wrapper.cpp:943-946). */
+int aix_tf_batch_ragged(aix_index_t* h, const char* bytes, const uint64_t* offsets, uint64_t N, uint32_t* out);
+int aix_tf_batch_ragged_dev(aix_index_t* h, const char* d_bytes, const uint64_t* d_offsets, uint64_t N,
+                            uint32_t* d_out, void* stream);
+
+/* get_hash_values / get_hash_value (python_wrapper.cpp:629-642): raw mphf::lookup of the bytes */
+int aix_hash_batch_ascii(aix_index_t* h, const char* kmers, uint64_t N, uint64_t* out);
+int aix_hash_batch_ascii_dev(aix_index_t* h, const char* d_kmers, uint64_t N, uint64_t* d_out, void* stream);
+/* get_kid_by_kmer (:700-716; 0 when absent) and get_strand (:726-742; 0 absent,1 fwd,2 rc) */
+int aix_kid_strand_batch_ascii(aix_index_t* h, const char* kmers, uint64_t N, uint64_t* kid_out /* nullable */,
+                               uint8_t* strand_out /* nullable */);
+int aix_kid_strand_batch_ascii_dev(aix_index_t* h, const char* d_kmers, uint64_t N, uint64_t* d_kid,
+                                   uint8_t* d_strand, void* stream);
+/* get_tf_both_directions_{23,13}mer_batch (:594-608,1259-1286) and, summed, get_total_tf_values_*
+ * (:548-562,1230-1257). Both directions are written as u64; either pointer may be NULL. */
+int aix_tf_both_batch_ascii(aix_index_t* h, const char* kmers, uint64_t N, uint64_t* fwd_out, uint64_t* rc_out);
+int aix_tf_both_batch_ascii_dev(aix_index_t* h, const char* d_kmers, uint64_t N, uint64_t* d_fwd,
+                                uint64_t* d_rc, void* stream);
+int aix_tf_total_batch_ascii(aix_index_t* h, const char* kmers, uint64_t N, uint64_t* out);
+int aix_tf_total_batch_ascii_dev(aix_index_t* h, const char* d_kmers, uint64_t N, uint64_t* d_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Coverage. replaces AIndex.get_sequence_coverage (aindex/core/aindex.py:314-322) for M sequences:
+ * sequence s = seqs[offs[s] .. offs[s+1]); for every window i of length k (k = handle's k):
+ * out[out_offs[s] + i] = tf >= cutoff ? tf : 0, tf as aix_tf_batch_ascii would give for that window.
+ * out_offs[s+1]-out_offs[s] must be >= max(0, len_s - k + 1).
+ * ------------------------------------------------------------------------------------------ */
+int aix_coverage_batch(aix_index_t* h, const char* seqs, const uint64_t* offs, uint64_t M, uint32_t cutoff,
+                       uint32_t* out, const uint64_t* out_offs);
+int aix_coverage_batch_dev(aix_index_t* h, const char* d_seqs, const uint64_t* d_offs, uint64_t M,
+                           uint64_t total_bytes, uint32_t cutoff, uint32_t* d_out, const uint64_t* d_out_offs,
+                           void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Counting.
+ * aix_count13: replaces Kmer13Counter (count_kmers13.cpp:113-161,194-272,358-388): every length-13
+ *   window of upper-cased ACGT in every sequence adds 1 to counts[mphf13(window)] (forward strand).
+ *   tf_out = u64[4^13] in mphf order — byte-identical to the reference's output file. The handle's
+ *   own tf table is NOT modified. `_dev`: d_buf must be in PLAIN form (one sequence per line, any
+ *   non-ACGT byte breaks a window); use aix_normalize_reads for FASTA/FASTQ.
+ * aix_count23_fixed: histogram of 23-mer windows against the handle's fixed key set (what
+ *   kmer_counter -> compute_index would store for these reads, restricted to keys in the index):
+ *   window chars valid per count_kmers.cpp:71-88 (ACGTU any case), key = canonical per canon_mode,
+ *   tf_out[slot] += 1 when checker[slot] == key. tf_out = u32[n]. Multi-GPU: each rank counts its
+ *   shard, then all-reduce(sum) tf_out (aindex_amd/dist.py).
+ * ------------------------------------------------------------------------------------------ */
+int aix_count13(aix_index_t* h, const char* buf, uint64_t len, int format, uint64_t* tf_out);
+int aix_count13_dev(aix_index_t* h, const char* d_plain, uint64_t len, uint64_t* d_tf_out, void* stream);
+int aix_count23_fixed(aix_index_t* h, const char* buf, uint64_t len, int format, int canon_mode, uint32_t* tf_out);
+int aix_count23_fixed_dev(aix_index_t* h, const char* d_plain, uint64_t len, int canon_mode,
+                          uint32_t* d_tf_out /* accumulated into, caller zeroes */, void* stream);
+/* Host-side record normalisation to PLAIN form (readers of count_kmers13.cpp:211-272 /
+ * count_kmers.cpp:250-295): out must hold len+1 bytes; *out_len receives the normalised length.
+ * fasta_mode: 0 = count_kmers13 rules, 1 = kmer_counter rules ('>' anywhere starts a record). */
+int aix_normalize_reads(const char* buf, uint64_t len, int format, int fasta_mode, char* out, uint64_t* out_len);
+int aix_detect_format(const char* buf, uint64_t len);  /* count_kmers13.cpp:194-206 */
+
+/* ------------------------------------------------------------------------------------------
+ * Synthetic inputs generated directly in HBM (mirrored by aindex_amd/synth.py).
+ * ------------------------------------------------------------------------------------------ */
+int aix_synth_genome_dev(uint64_t seed, uint64_t length, char* d_out, void* stream);
+int aix_synth_kmers_dev(uint64_t seed, uint64_t first, uint64_t N, int k, char* d_out, void* stream);
+int aix_synth_reads_dev(uint64_t seed, const char* d_genome, uint64_t genome_len, uint64_t first_read,
+                        uint64_t n_reads, uint32_t read_len, int rc_half, uint32_t n_rate_ppm,
+                        char* d_out /* n_reads*(read_len+1) */, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * MWHC builder (host code, like the reference's). replaces `compute_mphf_seq <keys.txt> <out.pf>`
+ * (src/emphf/compute_mphf_generic.hpp:19-61, mphf.hpp:21-67, hypergraph_sorter_seq.hpp:29-102):
+ * bit-identical .pf image for the same key list (same mt19937_64(37) seed stream, peeling order
+ * and value assignment). *pf_out is malloc'd; release with aix_free. AIX_ERR_CONFLICT when the key
+ * list is not peelable after 64 seeds (duplicate keys; the reference would loop forever).
+ * ------------------------------------------------------------------------------------------ */
+int aix_pf_build(const char* keys /* n*key_len bytes */, uint64_t n, uint32_t key_len, void** pf_out, uint64_t* pf_len);
+int aix_pf_build_ragged(const char* bytes, const uint64_t* offsets /* n+1 */, uint64_t n, void** pf_out, uint64_t* pf_len);
+int aix_pf_build_all_13mers(void** pf_out, uint64_t* pf_len);   /* generate_all_13mers + build_13mer_hash */
+void aix_free(void* p);
+
+/* self-test hook for the CPU test-suite: the exact-modulo used by the kernels, run on the host */
+uint64_t aix_selftest_mod(uint64_t h, uint64_t d);
+uint64_t aix_selftest_revcomp(uint64_t code, int k);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AINDEX_HIP_H */

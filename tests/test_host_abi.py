@@ -1,0 +1,103 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports every symbol declared in
+include/aindex_hip.h, exact-modulo / codec self-tests, MWHC builder bit-identity with the reference's
+compute_mphf_seq (golden .pf), record normalisation. No GPU compute calls."""
+import hashlib
+import json
+import os
+
+import ctypes as C
+import numpy as np
+import pytest
+
+from aindex_amd import _lib, builder, synth
+import oracle_lib as O
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.lib()
+    declared = _lib.header_symbols()
+    assert len(declared) >= 40
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in aindex_hip.h but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
+    assert b"gfx950" in L.aix_version()
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.AixError):
+        _lib.device_count()
+    h = C.c_void_p()
+    st = _lib.lib().aix_index_open_23(b"/nonexistent.pf", b"/x", b"/y", 0, C.byref(h))
+    assert st != 0
+
+
+def test_fastmod_exact():
+    L = _lib.lib()
+    rng = np.random.default_rng(5)
+    ds = [1, 2, 3, 5, 7, 255, 256, 257, 65535, 65536, 1664, 27514635, 20500001, 2 ** 31 - 1, 2 ** 31, 2 ** 31 + 1,
+          2 ** 32 - 1, 2 ** 32, 2 ** 32 + 1, 2 ** 40 + 12345, 2 ** 63 + 1] + [int(x) for x in rng.integers(1, 2 ** 32, 200)]
+    hs = [0, 1, 2 ** 32 - 1, 2 ** 32, 2 ** 32 + 1, 2 ** 64 - 1, 2 ** 64 - 2, 2 ** 63] + [int(x) for x in rng.integers(0, 2 ** 64, 400, dtype=np.uint64)]
+    for d in ds:
+        for h in hs + [d - 1, d, d + 1, 2 * d, (2 ** 64 - 1) // d * d, ((2 ** 64 - 1) // d * d - 1) % 2 ** 64]:
+            h %= 2 ** 64
+            assert L.aix_selftest_mod(h, d) == h % d, (h, d)
+
+
+def test_revcomp_matches_reference_codec(gold):
+    L = _lib.lib()
+    k = json.load(open(os.path.join(gold, "codec_kat.json")))
+    for e, r in zip(k["enc23"], k["rev23"]):
+        assert L.aix_selftest_revcomp(e, 23) == r
+    for e, r in zip(k["enc13"], k["rev13"]):
+        assert L.aix_selftest_revcomp(e, 13) == r
+
+
+def test_builder_bit_identical_small23(small23_prefix):
+    rows = [ln.split("\t")[0] for ln in open(small23_prefix + ".dat").read().split("\n") if ln]
+    want = open(small23_prefix + ".pf", "rb").read()
+    assert builder.build_pf(rows) == want
+    assert builder.build_pf_fixed("".join(rows).encode(), 23) == want
+
+
+def test_builder_rejects_duplicates():
+    with pytest.raises(_lib.AixError):
+        builder.build_pf(["ACGTACGTACGTACGTACGTACG"] * 4)
+
+
+def test_builder_random_sets_are_minimal_perfect():
+    for n, seed in ((1, 1), (3, 2), (37, 3), (5000, 4)):   # n=2 gives hash domain 1: never peelable, also in the reference
+        kmers = np.unique(synth.random_kmers_ascii(seed, n, 23), axis=0)
+        pf = builder.build_pf_fixed(kmers, 23)
+        path = f"/tmp/aix_t_{n}.pf"
+        open(path, "wb").write(pf)
+        m = O.OracleMphf(path)
+        got = sorted(m.lookup(bytes(k)) for k in kmers)
+        assert got == list(range(kmers.shape[0]))
+
+
+@pytest.mark.parametrize("name", ["refdata_test.fasta", "refdata_test_se.fastq", "refdata_test_reads.txt", "synth.fa", "synth.fq", "synth.txt"])
+def test_normalize_then_plain_rule_equals_reader(gold, name):
+    """aix_normalize_reads + the PLAIN window rule == the reference's per-format readers (via the oracle)."""
+    from pf13 import pf13_path
+    buf = open(os.path.join(gold, "count13", name), "rb").read()
+    a = np.frombuffer(buf, dtype=np.uint8)
+    out = np.empty(a.shape[0] + 2, dtype=np.uint8)
+    n = C.c_uint64()
+    _lib.check(_lib.lib().aix_normalize_reads(a.ctypes.data_as(C.c_void_p), a.shape[0], -1, 0, out.ctypes.data_as(C.c_void_p), C.byref(n)))
+    plain = out[: n.value].tobytes()
+    m = O.OracleMphf(pf13_path())
+    assert np.array_equal(O.count13(m, plain, 0), O.count13(m, buf, -1))
+
+
+def test_normalize_kmer_counter_rules(gold):
+    buf = open(os.path.join(gold, "kmer_counter", "mixed.fa"), "rb").read()
+    a = np.frombuffer(buf, dtype=np.uint8)
+    out = np.empty(a.shape[0] + 2, dtype=np.uint8)
+    n = C.c_uint64()
+    _lib.check(_lib.lib().aix_normalize_reads(a.ctypes.data_as(C.c_void_p), a.shape[0], 1, 1, out.ctypes.data_as(C.c_void_p), C.byref(n)))
+    lines = out[: n.value].tobytes().split(b"\n")
+    assert lines[-1] == b"" and all(b">" not in ln and b"\r" not in ln for ln in lines)
+    assert len(lines) - 1 == buf.count(b">")
