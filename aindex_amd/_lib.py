@@ -74,6 +74,7 @@ SIGNATURES = {
     "aix_count13_dev": (i32, [vp, vp, u64, vp, vp]),
     "aix_count23_fixed": (i32, [vp, vp, u64, i32, i32, vp]),
     "aix_count23_fixed_dev": (i32, [vp, vp, u64, i32, vp, vp]),
+    "aix_window_codes_dev": (i32, [vp, u64, i32, i32, vp, vp]),
     "aix_normalize_reads": (i32, [vp, u64, i32, i32, vp, C.POINTER(u64)]),
     "aix_detect_format": (i32, [vp, u64]),
     "aix_synth_genome_dev": (i32, [u64, u64, vp, vp]),
@@ -81,6 +82,9 @@ SIGNATURES = {
     "aix_synth_reads_dev": (i32, [u64, vp, u64, u64, u64, u32, i32, u32, vp, vp]),
     "aix_pf_build": (i32, [vp, u64, u32, C.POINTER(vp), C.POINTER(u64)]),
     "aix_pf_build_ragged": (i32, [vp, vp, u64, C.POINTER(vp), C.POINTER(u64)]),
+    "aix_pf_build_codes": (i32, [vp, u64, i32, C.POINTER(vp), C.POINTER(u64)]),
+    "aix_index_scatter": (i32, [vp, u64, vp, vp, u64, i32, vp, vp]),
+    "aix_index_build_23_codes_dev": (i32, [vp, u64, vp, vp, u64, i32, vp, C.POINTER(vp)]),
     "aix_pf_build_all_13mers": (i32, [C.POINTER(vp), C.POINTER(u64)]),
     "aix_free": (None, [vp]),
     "aix_selftest_mod": (u64, [u64, u64]),

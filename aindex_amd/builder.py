@@ -40,6 +40,14 @@ def build_pf(keys: Sequence) -> bytes:
     return _take(p, n)
 
 
+def build_pf_codes(codes: np.ndarray, k: int) -> bytes:
+    """keys given as 2-bit codes (first base most significant); hashed as their ASCII strings."""
+    c = np.ascontiguousarray(codes, dtype=np.uint64)
+    p, n = vp(), C.c_uint64()
+    check(lib().aix_pf_build_codes(c.ctypes.data_as(vp), c.shape[0], k, C.byref(p), C.byref(n)), "aix_pf_build_codes")
+    return _take(p, n)
+
+
 def build_all_13mers_pf(path: str | None = None) -> bytes:
     """The MPHF over all 4^13 13-mers in 2-bit order (generate_all_13mers + compute_mphf_seq)."""
     p, n = vp(), C.c_uint64()

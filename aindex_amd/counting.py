@@ -1,0 +1,61 @@
+"""Distinct k-mer counting on the GPU — the K1 row (replaces the reference's `kmer_counter`).
+
+window codes (hand-written HIP kernel, csrc/aix_kernels.hip:k_window_codes) -> device radix sort +
+run-length (torch.unique -> rocPRIM). Output = the (k-mer, count) set the reference writes to
+./output.txt (count_kmers.cpp:362-382), as arrays sorted by key; the reference's own order is
+"count descending, ties unspecified", so parity is on the set.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib, vp
+
+INVALID = 0xFFFFFFFFFFFFFFFF
+
+
+def normalize(buf: bytes, fmt: int = _lib.FMT_AUTO, fasta_mode: int = 1) -> bytes:
+    """Host-side record normalisation to PLAIN form (see aix_normalize_reads)."""
+    a = np.frombuffer(buf, dtype=np.uint8)
+    out = np.empty(a.shape[0] + 2, dtype=np.uint8)
+    n = C.c_uint64()
+    check(lib().aix_normalize_reads(a.ctypes.data_as(vp), a.shape[0], fmt, fasta_mode, out.ctypes.data_as(vp), C.byref(n)),
+          "aix_normalize_reads")
+    return out[: n.value].tobytes()
+
+
+def window_codes_t(plain_t, k: int, canon_mode: int):
+    """int64 tensor (u64 bit patterns) of len-k+1 canonical window codes; -1 (= ~0) marks invalid windows."""
+    import torch
+    n = plain_t.numel()
+    out = torch.empty(max(n - k + 1, 0), dtype=torch.int64, device=plain_t.device)
+    if out.numel():
+        with torch.cuda.device(plain_t.device):
+            check(lib().aix_window_codes_dev(vp(plain_t.data_ptr()), n, k, canon_mode, vp(out.data_ptr()),
+                                             vp(torch.cuda.current_stream().cuda_stream)), "aix_window_codes_dev")
+    return out
+
+
+def count_distinct_t(plain_t, k: int, canon_mode: int = _lib.CANON_TRUE_RC, min_count: int = 1):
+    """(keys int64 tensor sorted ascending, counts int64 tensor) for a PLAIN buffer already in HBM."""
+    import torch
+    codes = window_codes_t(plain_t, k, canon_mode)
+    codes = codes[codes != -1]
+    keys, counts = torch.unique(codes, sorted=True, return_counts=True)
+    if min_count > 1:
+        keep = counts >= min_count
+        keys, counts = keys[keep], counts[keep]
+    return keys, counts
+
+
+def count_distinct(buf: bytes, k: int, canon_mode: int = _lib.CANON_TRUE_RC, min_count: int = 1, fmt: int = _lib.FMT_FASTA,
+                   device: int = 0):
+    """kmer_counter replacement for a host buffer. Returns (keys uint64, counts uint64) sorted by key."""
+    import torch
+    plain = normalize(buf, fmt, 1)
+    t = torch.frombuffer(bytearray(plain) if plain else bytearray(1), dtype=torch.uint8)[: len(plain)].to(f"cuda:{device}")
+    keys, counts = count_distinct_t(t, k, canon_mode, min_count)
+    return keys.cpu().numpy().view(np.uint64), counts.cpu().numpy().astype(np.uint64)

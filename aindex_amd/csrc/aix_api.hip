@@ -41,6 +41,12 @@ struct DevGuard {   // switch to the handle's device for the duration of a call,
     ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
+struct DevBuf {
+    void* p = nullptr;
+    hipError_t alloc(uint64_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
 struct aix_index {
     int device = 0;
     uint32_t k = 0;
@@ -184,6 +190,24 @@ static void destroy(aix_index* h) {
     delete h;
 }
 
+// interleave device-resident checker[]/tf[] into KeyRec records and detect an all-canonical key set
+static int adopt_device_arrays(aix_index* h, const uint64_t* d_checker, const uint32_t* d_tf, uint64_t n, hipStream_t s) {
+    if (n == 0) return AIX_OK;
+    uint32_t* d_flag = nullptr;
+    HIPCHK(hipMalloc((void**)&h->keys, sizeof(KeyRec) * n));
+    h->device_bytes += sizeof(KeyRec) * n;
+    HIPCHK(hipMalloc((void**)&d_flag, 4));
+    hipError_t e = hipMemsetAsync(d_flag, 0, 4, s);
+    if (e == hipSuccess) e = launch_build_keyrecs(d_checker, d_tf, n, h->keys, d_flag, s);
+    uint32_t flag = 1;
+    if (e == hipSuccess) e = hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_flag);
+    HIPCHK(e);
+    h->canonical_only = (flag == 0);
+    return AIX_OK;
+}
+
 extern "C" int aix_index_create_23(const void* pf_bytes, uint64_t pf_len, const uint64_t* checker, const uint32_t* tf, uint64_t n, int device,
                                    aix_index_t** out) {
     if (!pf_bytes || !out || (n && (!checker || !tf))) return AIX_ERR_ARG;
@@ -195,28 +219,91 @@ extern "C" int aix_index_create_23(const void* pf_bytes, uint64_t pf_len, const 
     if (!h) return AIX_ERR_NOMEM;
     h->device = device; h->k = 23; h->n = n;
     DevGuard g(device);
-    auto fail = [&](int code) { destroy(h); return code; };
     st = upload_mphf(h, (const uint8_t*)pf_bytes, pf_len);
-    if (st) return fail(st);
-    if (n) {
-        uint64_t* d_checker = nullptr; uint32_t* d_tf = nullptr; uint32_t* d_flag = nullptr;
-        hipError_t e = hipMalloc((void**)&h->keys, sizeof(KeyRec) * n);
-        if (e == hipSuccess) e = hipMalloc((void**)&d_checker, 8 * n);
-        if (e == hipSuccess) e = hipMalloc((void**)&d_tf, 4 * n);
-        if (e == hipSuccess) e = hipMalloc((void**)&d_flag, 4);
-        if (e == hipSuccess) e = hipMemcpy(d_checker, checker, 8 * n, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(d_tf, tf, 4 * n, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemset(d_flag, 0, 4);
-        if (e == hipSuccess) e = launch_build_keyrecs(d_checker, d_tf, n, h->keys, d_flag, 0);
-        uint32_t flag = 1;
-        if (e == hipSuccess) e = hipMemcpy(&flag, d_flag, 4, hipMemcpyDeviceToHost);
-        if (d_checker) (void)hipFree(d_checker);
-        if (d_tf) (void)hipFree(d_tf);
-        if (d_flag) (void)hipFree(d_flag);
-        if (e != hipSuccess) { set_last_error(std::string("index upload: ") + hipGetErrorString(e)); return fail(AIX_ERR_HIP); }
-        h->device_bytes += sizeof(KeyRec) * n;
-        h->canonical_only = (flag == 0);
+    if (!st && n) {
+        DevBuf dc, dt;
+        hipError_t e = dc.alloc(8 * n);
+        if (e == hipSuccess) e = dt.alloc(4 * n);
+        if (e == hipSuccess) e = hipMemcpy(dc.p, checker, 8 * n, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(dt.p, tf, 4 * n, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { set_last_error(std::string("index upload: ") + hipGetErrorString(e)); st = AIX_ERR_HIP; }
+        else st = adopt_device_arrays(h, (const uint64_t*)dc.p, (const uint32_t*)dt.p, n, 0);
     }
+    if (st) { destroy(h); return st; }
+    *out = h;
+    return AIX_OK;
+}
+
+// I1 on the device: scatter (key, count) pairs through the MPHF. Exactly one of d_keys / d_codes is set.
+static int scatter_device(aix_index* h, uint64_t n, const uint8_t* d_keys, const uint64_t* d_codes, const uint32_t* d_counts, uint64_t* d_checker,
+                          uint32_t* d_tf, hipStream_t s) {
+    DevBuf occ, flag;
+    const uint64_t occ_bytes = 4 * ((n + 31) / 32);
+    HIPCHK(occ.alloc(occ_bytes));
+    HIPCHK(flag.alloc(4));
+    HIPCHK(hipMemsetAsync(occ.p, 0, occ_bytes, s));
+    HIPCHK(hipMemsetAsync(flag.p, 0, 4, s));
+    HIPCHK(hipMemsetAsync(d_checker, 0, 8 * n, s));            // hash.cpp:836-844: arrays start zeroed
+    HIPCHK(hipMemsetAsync(d_tf, 0, 4 * n, s));
+    const IndexDev d = h->dev();
+    HIPCHK(launch_scatter23(d.m, n, d_keys, d_codes, d_counts, d_checker, d_tf, (uint32_t*)occ.p, (uint32_t*)flag.p, s));
+    uint32_t conflicts = 0;
+    HIPCHK(hipMemcpyAsync(&conflicts, flag.p, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return conflicts ? AIX_ERR_CONFLICT : AIX_OK;
+}
+
+extern "C" int aix_index_scatter(const void* pf_bytes, uint64_t pf_len, const char* keys, const uint32_t* counts, uint64_t n, int device,
+                                 uint64_t* checker_out, uint32_t* tf_out) {
+    if (!pf_bytes || !keys || !checker_out || !tf_out || n == 0) return AIX_ERR_ARG;
+    int st = check_device(device);
+    if (st) return st;
+    aix_index tmp;
+    tmp.device = device; tmp.k = 23; tmp.n = n;
+    DevGuard g(device);
+    st = upload_mphf(&tmp, (const uint8_t*)pf_bytes, pf_len);
+    if (!st) {
+        DevBuf dk, dcnt, dc, dt;
+        hipError_t e = dk.alloc(23 * n + 8);
+        if (e == hipSuccess) e = dc.alloc(8 * n);
+        if (e == hipSuccess) e = dt.alloc(4 * n);
+        if (e == hipSuccess && counts) e = dcnt.alloc(4 * n);
+        if (e == hipSuccess) e = hipMemcpy(dk.p, keys, 23 * n, hipMemcpyHostToDevice);
+        if (e == hipSuccess && counts) e = hipMemcpy(dcnt.p, counts, 4 * n, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { set_last_error(std::string("scatter staging: ") + hipGetErrorString(e)); st = AIX_ERR_HIP; }
+        if (!st) st = scatter_device(&tmp, n, (const uint8_t*)dk.p, nullptr, counts ? (const uint32_t*)dcnt.p : nullptr, (uint64_t*)dc.p, (uint32_t*)dt.p, 0);
+        if (!st) {
+            e = hipMemcpy(checker_out, dc.p, 8 * n, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(tf_out, dt.p, 4 * n, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) { set_last_error(std::string("scatter readback: ") + hipGetErrorString(e)); st = AIX_ERR_HIP; }
+        }
+    }
+    if (tmp.recs) (void)hipFree(tmp.recs);
+    tmp.recs = nullptr;
+    return st;
+}
+
+extern "C" int aix_index_build_23_codes_dev(const void* pf_bytes, uint64_t pf_len, const uint64_t* d_codes, const uint32_t* d_counts, uint64_t n,
+                                            int device, void* stream, aix_index_t** out) {
+    if (!pf_bytes || !d_codes || !out || n == 0) return AIX_ERR_ARG;
+    *out = nullptr;
+    int st = check_device(device);
+    if (st) return st;
+    if (n >> 32) return AIX_ERR_UNSUPPORTED;
+    aix_index* h = new (std::nothrow) aix_index();
+    if (!h) return AIX_ERR_NOMEM;
+    h->device = device; h->k = 23; h->n = n;
+    DevGuard g(device);
+    st = upload_mphf(h, (const uint8_t*)pf_bytes, pf_len);
+    if (!st) {
+        DevBuf dc, dt;
+        hipError_t e = dc.alloc(8 * n);
+        if (e == hipSuccess) e = dt.alloc(4 * n);
+        if (e != hipSuccess) { set_last_error(std::string("index build: ") + hipGetErrorString(e)); st = AIX_ERR_HIP; }
+        if (!st) st = scatter_device(h, n, nullptr, d_codes, d_counts, (uint64_t*)dc.p, (uint32_t*)dt.p, (hipStream_t)stream);
+        if (!st) st = adopt_device_arrays(h, (const uint64_t*)dc.p, (const uint32_t*)dt.p, n, (hipStream_t)stream);
+    }
+    if (st) { destroy(h); return st; }
     *out = h;
     return AIX_OK;
 }
@@ -450,6 +537,14 @@ extern "C" int aix_count23_fixed_dev(aix_index_t* h, const char* d_plain, uint64
     return AIX_OK;
 }
 
+extern "C" int aix_window_codes_dev(const char* d_plain, uint64_t len, int k, int canon_mode, uint64_t* d_codes, void* stream) {
+    if ((len && !d_plain) || k < 1 || k > 32 || canon_mode < 0 || canon_mode > 2) return AIX_ERR_ARG;
+    if (len < (uint64_t)k) return AIX_OK;
+    if (!d_codes) return AIX_ERR_ARG;
+    HIPCHK(launch_window_codes((const uint8_t*)d_plain, len, k, canon_mode, d_codes, (hipStream_t)stream));
+    return AIX_OK;
+}
+
 extern "C" int aix_synth_genome_dev(uint64_t seed, uint64_t length, char* d_out, void* stream) {
     if (length && !d_out) return AIX_ERR_ARG;
     HIPCHK(launch_synth_genome(seed, length, (uint8_t*)d_out, (hipStream_t)stream));
@@ -471,11 +566,6 @@ extern "C" int aix_synth_reads_dev(uint64_t seed, const char* d_genome, uint64_t
 // ---------------------------------------------------------------------------------------------
 // host-pointer twins: stage through HBM in bounded chunks, run the same kernels, copy back
 // ---------------------------------------------------------------------------------------------
-struct DevBuf {
-    void* p = nullptr;
-    hipError_t alloc(uint64_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
-    ~DevBuf() { if (p) (void)hipFree(p); }
-};
 static constexpr uint64_t kChunk = 1ull << 26;   // queries per staging chunk (64 Mi)
 
 template <typename F>

@@ -31,12 +31,14 @@ struct KeySource {
     uint64_t stride;
     uint64_t n;
     bool all13;             // keys are the 4^13 13-mers in 2-bit order, generated on the fly
+    const uint64_t* codes = nullptr;   // keys are ASCII renderings of 2-bit codes of length `stride`
     inline void get(uint64_t i, const uint8_t*& p, uint64_t& len, uint8_t* tmp) const {
-        if (all13) {
+        if (all13 || codes) {
             static const char L[4] = {'A', 'C', 'G', 'T'};
-            uint64_t x = i;
-            for (int j = 12; j >= 0; --j) { tmp[j] = (uint8_t)L[x & 3]; x >>= 2; }
-            p = tmp; len = 13;
+            uint64_t x = codes ? codes[i] : i;
+            const int k = codes ? (int)stride : 13;
+            for (int j = k - 1; j >= 0; --j) { tmp[j] = (uint8_t)L[x & 3]; x >>= 2; }
+            p = tmp; len = (uint64_t)k;
         } else if (offs) {
             p = bytes + offs[i]; len = offs[i + 1] - offs[i];
         } else {
@@ -75,7 +77,7 @@ static bool try_peel(const KeySource& ks, uint64_t D, uint64_t seed, int nthread
         for (int t = 0; t < nthreads; ++t) {
             const uint64_t lo = std::min<uint64_t>(n, per * t), hi = std::min<uint64_t>(n, lo + per);
             th.emplace_back([&, lo, hi]() {
-                uint8_t tmp[16];
+                uint8_t tmp[32];
                 for (uint64_t i = lo; i < hi; ++i) {
                     const uint8_t* p; uint64_t len;
                     ks.get(i, p, len, tmp);
@@ -197,6 +199,11 @@ extern "C" int aix_pf_build(const char* keys, uint64_t n, uint32_t key_len, void
 extern "C" int aix_pf_build_ragged(const char* bytes, const uint64_t* offsets, uint64_t n, void** pf_out, uint64_t* pf_len) {
     if (!bytes || !offsets || n == 0) return AIX_ERR_ARG;
     KeySource ks{(const uint8_t*)bytes, offsets, 0, n, false};
+    return build(ks, pf_out, pf_len);
+}
+extern "C" int aix_pf_build_codes(const uint64_t* codes, uint64_t n, int k, void** pf_out, uint64_t* pf_len) {
+    if (!codes || n == 0 || k < 1 || k > 32) return AIX_ERR_ARG;
+    KeySource ks{nullptr, nullptr, (uint64_t)k, n, false, codes};
     return build(ks, pf_out, pf_len);
 }
 extern "C" int aix_pf_build_all_13mers(void** pf_out, uint64_t* pf_len) {

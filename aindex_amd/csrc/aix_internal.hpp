@@ -38,6 +38,8 @@ hipError_t launch_coverage(const IndexDev& ix, const uint8_t* seqs, const uint64
 
 // index construction helpers
 hipError_t launch_build_keyrecs(const uint64_t* checker, const uint32_t* tf, uint64_t n, KeyRec* recs, uint32_t* noncanon_count, hipStream_t s);
+hipError_t launch_scatter23(const MphfDev& m, uint64_t n, const uint8_t* keys_ascii /* or */, const uint64_t* codes, const uint32_t* counts,
+                            uint64_t* checker, uint32_t* tf, uint32_t* occupied_bits, uint32_t* conflict, hipStream_t s);
 hipError_t launch_perm13(const MphfDev& m, uint32_t* perm /* [4^13]: code -> mphf index */, hipStream_t s);
 hipError_t launch_tf13_to_code_order(const uint32_t* perm, const uint64_t* tf_mphf, uint64_t* tf_code, hipStream_t s);
 hipError_t launch_extract_tf(const KeyRec* recs, uint64_t n, uint32_t* tf, uint64_t* checker, hipStream_t s);
@@ -46,6 +48,8 @@ hipError_t launch_extract_tf(const KeyRec* recs, uint64_t n, uint32_t* tf, uint6
 hipError_t launch_count13_plain(const uint8_t* buf, uint64_t len, unsigned long long* table_code /* [4^13] */, hipStream_t s);
 hipError_t launch_scatter13_to_mphf(const uint32_t* perm, const unsigned long long* table_code, uint64_t* out_mphf, hipStream_t s);
 hipError_t launch_count23_fixed(const IndexDev& ix, const uint8_t* buf, uint64_t len, int canon_mode, uint32_t* tf_out, hipStream_t s);
+
+hipError_t launch_window_codes(const uint8_t* buf, uint64_t len, int k, int canon_mode, uint64_t* out /* [len-k+1] */, hipStream_t s);
 
 // synthetic generators
 hipError_t launch_synth_genome(uint64_t seed, uint64_t length, uint8_t* out, hipStream_t s);

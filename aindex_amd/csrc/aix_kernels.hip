@@ -352,6 +352,34 @@ __global__ void __launch_bounds__(kBlock) k_extract(const KeyRec* __restrict__ r
         if (checker) checker[i] = r.code;
     }
 }
+// I1 (hash.cpp:671-723): checker[h] = code, tf[h] = count with h = mphf(key). Keys arrive either as
+// n x 23 ASCII bytes (the .dat lines) or as 2-bit codes. A slot hit twice raises `conflict`
+// (the reference detects it only when the earlier tf was non-zero, then exit(12)).
+template <bool ASCII>
+__global__ void __launch_bounds__(kBlock) k_scatter23(const MphfDev m, uint64_t n, const uint8_t* __restrict__ keys, const uint64_t* __restrict__ codes,
+                                                     const uint32_t* __restrict__ counts, uint64_t* __restrict__ checker, uint32_t* __restrict__ tf,
+                                                     uint32_t* __restrict__ occupied, uint32_t* __restrict__ conflict) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        uint64_t w0, w1, w2, code;
+        if (ASCII) {
+            load23(keys + 23 * i, w0, w1, w2);
+            code = encode23_words(w0, w1, w2).code;                 // get_dna23_bitset(kmer), hash.cpp:715
+        } else {
+            code = codes[i] & ((1ULL << 46) - 1);
+            ascii23_of_rc(revcomp(code, 23), w0, w1, w2);
+        }
+        uint64_t a, b, c;
+        jenkins23(w0, w1, w2, m.seed, a, b, c);
+        const uint64_t h = mphf_from_hash(m, a, b, c);
+        if (h >= n) { atomicAdd(conflict, 1u); continue; }
+        const uint32_t bit = 1u << (h & 31);
+        if (atomicOr(&occupied[h >> 5], bit) & bit) { atomicAdd(conflict, 1u); continue; }
+        checker[h] = code;
+        tf[h] = counts ? counts[i] : 0u;
+    }
+}
+
 // perm[code] = mphf13(ASCII(code)) for all 4^13 codes
 __global__ void __launch_bounds__(kBlock) k_perm13(const MphfDev m, uint32_t* __restrict__ perm) {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
@@ -420,6 +448,48 @@ __global__ void __launch_bounds__(kBlock) k_count23_fixed(const IndexDev ix, con
         ascii23_of_rc(revcomp(key, 23), s0, s1, s2);
         const Probe pr = probe23(ix, s0, s1, s2, key);
         if (pr.found) atomicAdd(&tf_out[pr.slot], 1u);
+    }
+}
+
+// K1 front end (count_kmers.cpp:93-136,297-308): the canonical 2-bit code of every window of a PLAIN
+// buffer, ~0 where the window holds a non-base byte. Distinct counting = sort + run-length of this.
+template <int K>
+__global__ void __launch_bounds__(kBlock) k_window_codes(const uint8_t* __restrict__ buf, uint64_t len, int k, int canon_mode, uint64_t* __restrict__ out) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    if (len < (uint64_t)k) return;
+    const uint64_t nwin = len - k + 1;
+    for (uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x; p < nwin; p += stride) {
+        uint64_t code = 0;
+        bool valid = true;
+        if (K == 23) {
+            uint64_t w0, w1, w2;
+            load23(buf + p, w0, w1, w2);
+            w0 = u_to_t(w0 & 0xDFDFDFDFDFDFDFDFULL);
+            w1 = u_to_t(w1 & 0xDFDFDFDFDFDFDFDFULL);
+            w2 = u_to_t(w2 & 0x00DFDFDFDFDFDFDFULL);
+            const Enc23 e = encode23_words(w0, w1, w2);
+            code = e.code; valid = e.valid;
+        } else if (K == 13) {
+            uint64_t w0, w1;
+            load13(buf + p, w0, w1);
+            w0 = u_to_t(w0 & 0xDFDFDFDFDFDFDFDFULL);
+            w1 = u_to_t(w1 & 0x000000DFDFDFDFDFULL);
+            const Enc13 e = encode13_words(w0, w1);
+            code = e.code; valid = e.valid;
+        } else {
+            for (int j = 0; j < k; ++j) {
+                uint32_t c = buf[p + j] & 0xDFu;
+                c = c == 'U' ? 'T' : c;
+                const uint32_t v = c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u;
+                if (v == 4u) { valid = false; break; }
+                code = (code << 2) | v;
+            }
+        }
+        if (valid) {
+            if (canon_mode == 1) { const uint64_t x = revcomp_refx86(code, k); code = code < x ? code : x; }
+            else if (canon_mode == 2) { const uint64_t x = revcomp(code, k); code = code < x ? code : x; }
+        }
+        out[p] = valid ? code : ~0ULL;
     }
 }
 
@@ -532,6 +602,12 @@ hipError_t launch_extract_tf(const KeyRec* recs, uint64_t n, uint32_t* tf, uint6
     if (n == 0) return hipSuccess;
     AIX_LAUNCH(k_extract, n, s, recs, n, tf, checker);
 }
+hipError_t launch_scatter23(const MphfDev& m, uint64_t n, const uint8_t* keys, const uint64_t* codes, const uint32_t* counts, uint64_t* checker, uint32_t* tf,
+                            uint32_t* occupied, uint32_t* conflict, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    if (keys) AIX_LAUNCH(k_scatter23<true>, n, s, m, n, keys, codes, counts, checker, tf, occupied, conflict);
+    AIX_LAUNCH(k_scatter23<false>, n, s, m, n, keys, codes, counts, checker, tf, occupied, conflict);
+}
 hipError_t launch_perm13(const MphfDev& m, uint32_t* perm, hipStream_t s) { AIX_LAUNCH(k_perm13, 67108864ull, s, m, perm); }
 hipError_t launch_tf13_to_code_order(const uint32_t* perm, const uint64_t* tf_mphf, uint64_t* tf_code, hipStream_t s) {
     AIX_LAUNCH(k_tf13_to_code, 67108864ull, s, perm, tf_mphf, tf_code);
@@ -546,6 +622,12 @@ hipError_t launch_scatter13_to_mphf(const uint32_t* perm, const unsigned long lo
 hipError_t launch_count23_fixed(const IndexDev& ix, const uint8_t* buf, uint64_t len, int canon_mode, uint32_t* tf_out, hipStream_t s) {
     if (len < 23 || ix.n == 0) return hipSuccess;
     AIX_LAUNCH(k_count23_fixed, len - 22, s, ix, buf, len, canon_mode, tf_out);
+}
+hipError_t launch_window_codes(const uint8_t* buf, uint64_t len, int k, int canon_mode, uint64_t* out, hipStream_t s) {
+    if (len < (uint64_t)k) return hipSuccess;
+    if (k == 23) AIX_LAUNCH(k_window_codes<23>, len - k + 1, s, buf, len, k, canon_mode, out);
+    if (k == 13) AIX_LAUNCH(k_window_codes<13>, len - k + 1, s, buf, len, k, canon_mode, out);
+    AIX_LAUNCH(k_window_codes<0>, len - k + 1, s, buf, len, k, canon_mode, out);
 }
 hipError_t launch_synth_genome(uint64_t seed, uint64_t length, uint8_t* out, hipStream_t s) {
     if (length == 0) return hipSuccess;

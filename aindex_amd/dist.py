@@ -1,0 +1,77 @@
+"""Multi-GPU sharding: one process per GPU, reads / queries split into contiguous ranges,
+no data-path collective for lookups, one all-reduce(sum) of tf[] for counting (RCCL over xGMI when
+the backend is "nccl"; "gloo" on CPU for the tests)."""
+from __future__ import annotations
+
+import os
+from typing import Tuple
+
+
+def rank_world() -> Tuple[int, int, int]:
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+
+
+def init(backend: str | None = None):
+    """Initialise torch.distributed from the torchrun environment (no-op for a single process)."""
+    import torch
+    import torch.distributed as dist
+    rank, world, local = rank_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [lo, hi) share of `total` items; the first `total % world` ranks get one extra."""
+    base, extra = divmod(total, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_lines(buf: bytes, rank: int, world: int) -> bytes:
+    """Record-aligned byte range of a PLAIN buffer (cuts only after '\\n'), contiguous per rank."""
+    n = len(buf)
+    if world == 1:
+        return buf
+
+    def cut(pos):
+        if pos <= 0:
+            return 0
+        if pos >= n:
+            return n
+        j = buf.find(b"\n", pos - 1)
+        return n if j < 0 else j + 1
+
+    lo, hi = shard_range(n, rank, world)
+    return buf[cut(lo):cut(hi)]
+
+
+def all_reduce_sum_(t):
+    """In-place sum over ranks of an integer tensor (tf histograms). int32/int64 carry u32/u64 bit patterns:
+    two's-complement addition is the same as unsigned addition modulo 2^32 / 2^64."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def barrier():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def all_reduce_max_float(x: float, device=None) -> float:
+    import torch
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        t = torch.tensor([x], dtype=torch.float64, device=device if device is not None else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    return x

@@ -86,6 +86,20 @@ class Index:
         check(lib().aix_index_create_13(_np_ptr(buf), buf.shape[0], _np_ptr(tf), device, C.byref(h)), "aix_index_create_13")
         return cls(h)
 
+    @classmethod
+    def build_23_codes_t(cls, pf_bytes: bytes, keys_t, counts_t=None, device: Optional[int] = None) -> "Index":
+        """I1 on the device: scatter (2-bit code, count) pairs that already live in HBM through the MPHF and
+        keep the result resident. keys_t: int64/uint64 tensor; counts_t: int32 tensor or None (tf = 0)."""
+        import torch
+        dev = keys_t.device.index if device is None else device
+        h = vp()
+        buf = np.frombuffer(pf_bytes, dtype=np.uint8)
+        with torch.cuda.device(dev):
+            check(lib().aix_index_build_23_codes_dev(_np_ptr(buf), buf.shape[0], vp(keys_t.data_ptr()),
+                                                     vp(counts_t.data_ptr()) if counts_t is not None else None,
+                                                     keys_t.numel(), dev, _stream_ptr(), C.byref(h)), "aix_index_build_23_codes_dev")
+        return cls(h)
+
     def close(self):
         if self._h is not None and self._h.value:
             lib().aix_index_close(self._h)

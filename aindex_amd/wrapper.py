@@ -1,0 +1,304 @@
+"""AindexWrapper — drop-in counterpart of the reference's pybind11 class `aindex_cpp.AindexWrapper`
+(src/python_wrapper.cpp:130-1316, bindings :1320-2135) for the tf / hash / batch-query path.
+
+Same method names, argument meaning and return types; the work runs on the MI355X through
+libaindex_hip.so. Differences are limited to failure behaviour: where the reference calls
+std::terminate()/exit() (missing files: python_wrapper.cpp:265,413,1118) this class raises
+FileNotFoundError / AixError instead of killing the interpreter.
+
+Mode semantics preserved: get_tf_value(s) dispatch on `is_13mer_mode` — set by any
+13-mer load and never cleared — not on the k-mer length.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from .engine import Index
+
+TOTAL_13MERS = 4 ** 13
+_COMP = bytes.maketrans(b"ACGT", b"TGCA")
+
+
+def _enc(s) -> bytes:
+    return s.encode("latin-1") if isinstance(s, str) else bytes(s)
+
+
+class AindexWrapper:
+    def __init__(self, device: int = 0):
+        self._device = device
+        self._ix23: Optional[Index] = None
+        self._ix13: Optional[Index] = None
+        self._is_13mer_mode = False
+        self._tf13_host: Optional[np.ndarray] = None     # mmap of the 13-mer tf file (u64, mphf order)
+        self._checker_host: Optional[np.ndarray] = None
+        # read/write attributes of the reference class (python_wrapper.cpp:1820-1838)
+        self.aindex_loaded = False
+        self.n_reads = 0
+        self.n_kmers = 0
+        self.reads_size = 0
+
+    # ---- loaders -----------------------------------------------------------------------------
+    @staticmethod
+    def _need(*paths):
+        for p in paths:
+            if not os.path.exists(p):
+                raise FileNotFoundError(f"Required file not found: {p}")
+
+    def load(self, hash_filename: str, tf_file: str, kmers_bin_filename: str, kmers_text_filename: str = ""):
+        """python_wrapper.cpp:228-245 (kmers_text_filename is unused for k = 23, hash.cpp:388-423)."""
+        self._need(hash_filename, tf_file, kmers_bin_filename)
+        if self._ix23 is not None:
+            self._ix23.close()
+        self._ix23 = Index.open_23(hash_filename, tf_file, kmers_bin_filename, self._device)
+        self._checker_host = None
+        self.n_kmers = self._ix23.n
+
+    def load_hash_file(self, hash_filename: str, tf_file: str, kmers_bin_filename: str, kmers_text_filename: str = ""):
+        self.load(hash_filename, tf_file, kmers_bin_filename, kmers_text_filename)      # :247-259
+
+    def load_from_prefix_23mer(self, prefix: str, reads_file: str = ""):
+        """:1103-1132 — files prefix.pf / .tf.bin / .kmers.bin."""
+        self.load_hash_file(prefix + ".pf", prefix + ".tf.bin", prefix + ".kmers.bin", prefix + ".txt")
+        if reads_file:
+            self.load_reads(reads_file)
+
+    def load_13mer_index(self, hash_file: str, tf_file: str):
+        """:404-437 — tf file = u64[4^13] in mphf order (count_kmers13 output)."""
+        self._need(hash_file, tf_file)
+        if self._ix13 is not None:
+            self._ix13.close()
+        self._ix13 = Index.open_13(hash_file, tf_file, self._device)
+        self._tf13_host = np.memmap(tf_file, dtype=np.uint64, mode="r", shape=(TOTAL_13MERS,))
+        self._is_13mer_mode = True
+        self.n_kmers = TOTAL_13MERS
+
+    def load_from_prefix_13mer(self, prefix: str, reads_file: str = ""):
+        self.load_13mer_index(prefix + ".pf", prefix + ".tf.bin")                       # :1162-1188
+        if reads_file:
+            self.load_reads(reads_file)
+
+    # positions / reads access belong to the "next" tier
+    def load_reads(self, reads_file: str):
+        raise NotImplementedError("reads access (python_wrapper.cpp:281-359) is outside the hot path built so far")
+
+    def load_aindex(self, *a, **k):
+        raise NotImplementedError("position index loading (python_wrapper.cpp:361-402) is outside the hot path built so far")
+
+    load_aindex_from_prefix_23mer = load_aindex
+    load_13mer_aindex = load_aindex
+    load_aindex_from_prefix_13mer = load_aindex
+
+    # ---- helpers -----------------------------------------------------------------------------
+    def _need23(self) -> Index:
+        if self._ix23 is None:
+            raise RuntimeError("23-mer index not loaded (the reference dereferences a null hash_map here)")
+        return self._ix23
+
+    # ---- tf queries --------------------------------------------------------------------------
+    def get_tf_values(self, kmers: List[str]) -> List[int]:
+        """:653-664 — dispatch on is_13mer_mode."""
+        if self._is_13mer_mode:
+            return self.get_tf_values_13mer(kmers)
+        return self.get_tf_values_23mer(kmers)
+
+    def get_tf_value(self, kmer: str) -> int:
+        return self.get_tf_values([kmer])[0]                                            # :644-651
+
+    def get_tf_values_23mer(self, kmers: List[str]) -> List[int]:
+        if not kmers:
+            return []
+        return self._need23().tf_ragged(kmers).tolist()                                 # :1219-1228
+
+    def get_tf_value_23mer(self, kmer: str) -> int:
+        return self.get_tf_values_23mer([kmer])[0]
+
+    def get_tf_values_13mer(self, kmers: List[str]) -> List[int]:
+        """:938-980 (defined but not bound in the reference, although aindex.py:148 calls it)."""
+        if not self._is_13mer_mode:
+            return [0] * len(kmers)
+        if not kmers:
+            return []
+        return self._ix13.tf_ragged(kmers).tolist()
+
+    def get_tf_value_13mer(self, kmer: str) -> int:
+        return self.get_tf_values_13mer([kmer])[0] if self._is_13mer_mode and self._ix13 else 0
+
+    # numpy fast paths (zero Python-object overhead): (N, k) uint8 ASCII or flat bytes
+    def get_tf_values_array(self, kmers_u8) -> np.ndarray:
+        ix = self._ix13 if self._is_13mer_mode else self._need23()
+        return ix.tf_ascii(kmers_u8)
+
+    def _fixed(self, kmers: List[str], k: int):
+        """Split into the indices of length-k strings and their joined bytes (others answer 0)."""
+        bs = [_enc(s) for s in kmers]
+        idx = [i for i, b in enumerate(bs) if len(b) == k]
+        return idx, b"".join(bs[i] for i in idx)
+
+    def get_total_tf_values_23mer(self, kmers: List[str]) -> List[int]:
+        out = [0] * len(kmers)                                                          # :1230-1257; len != 23 -> 0
+        idx, data = self._fixed(kmers, 23)
+        if idx:
+            for i, v in zip(idx, self._need23().total_ascii(data).tolist()):
+                out[i] = v
+        return out
+
+    def get_total_tf_value_23mer(self, kmer: str) -> int:
+        return self.get_total_tf_values_23mer([kmer])[0]
+
+    def get_tf_both_directions_23mer_batch(self, kmers: List[str]) -> List[Tuple[int, int]]:
+        out = [(0, 0)] * len(kmers)                                                     # :1259-1286
+        idx, data = self._fixed(kmers, 23)
+        if idx:
+            f, r = self._need23().both_ascii(data)
+            for i, a, b in zip(idx, f.tolist(), r.tolist()):
+                out[i] = (a, b)
+        return out
+
+    def get_tf_both_directions_23mer(self, kmer: str) -> Tuple[int, int]:
+        return self.get_tf_both_directions_23mer_batch([kmer])[0]
+
+    def get_total_tf_values_13mer(self, kmers: List[str]) -> List[int]:
+        if not self._is_13mer_mode:                                                     # :548-562
+            return [0] * len(kmers)
+        out = [0] * len(kmers)
+        idx, data = self._fixed(kmers, 13)
+        if idx:
+            for i, v in zip(idx, self._ix13.total_ascii(data).tolist()):
+                out[i] = v
+        return out
+
+    def get_total_tf_value_13mer(self, kmer: str) -> int:
+        return self.get_total_tf_values_13mer([kmer])[0]
+
+    def get_tf_both_directions_13mer_batch(self, kmers: List[str]) -> List[Tuple[int, int]]:
+        if not self._is_13mer_mode:                                                     # :594-608
+            return [(0, 0)] * len(kmers)
+        out = [(0, 0)] * len(kmers)
+        idx, data = self._fixed(kmers, 13)
+        if idx:
+            f, r = self._ix13.both_ascii(data)
+            for i, a, b in zip(idx, f.tolist(), r.tolist()):
+                out[i] = (a, b)
+        return out
+
+    def get_tf_both_directions_13mer(self, kmer: str) -> Tuple[int, int]:
+        return self.get_tf_both_directions_13mer_batch([kmer])[0]
+
+    def get_13mer_tf_array(self) -> List[int]:
+        if not self._is_13mer_mode:                                                     # :983-991, u32-truncated copy
+            return []
+        return (np.asarray(self._tf13_host) & np.uint64(0xFFFFFFFF)).astype(np.uint32).tolist()
+
+    def get_13mer_tf_array_numpy(self) -> np.ndarray:
+        """Same data as get_13mer_tf_array without materialising 67 M Python ints."""
+        return (np.asarray(self._tf13_host) & np.uint64(0xFFFFFFFF)).astype(np.uint32) if self._is_13mer_mode else np.zeros(0, np.uint32)
+
+    def get_tf_by_index_13mer(self, index: int) -> int:
+        if not self._is_13mer_mode or index >= TOTAL_13MERS or index < 0:               # :993-998
+            return 0
+        return int(self._tf13_host[index]) & 0xFFFFFFFF
+
+    # ---- hash / ids --------------------------------------------------------------------------
+    def get_hash_values(self, kmers: List[str]) -> List[int]:
+        """:629-636 — raw mphf::lookup; only fixed 23-byte strings are supported here."""
+        idx, data = self._fixed(kmers, 23)
+        if len(idx) != len(kmers):
+            raise ValueError("get_hash_values: every k-mer must have length 23")
+        return self._need23().hash_ascii(data).tolist() if kmers else []
+
+    def get_hash_value(self, kmer: str) -> int:
+        return self.get_hash_values([kmer])[0]
+
+    def _kid_strand(self, kmer: str):
+        b = _enc(kmer)
+        if len(b) != 23:
+            return 0, 0
+        kid, strand = self._need23().kid_strand_ascii(b)
+        return int(kid[0]), int(strand[0])
+
+    def get_kid_by_kmer(self, kmer: str) -> int:
+        return self._kid_strand(kmer)[0]                                                # :700-716 (0 when absent)
+
+    def get_strand(self, kmer: str) -> int:
+        return self._kid_strand(kmer)[1]                                                # :726-742
+
+    def _checker(self) -> np.ndarray:
+        if self._checker_host is None:
+            self._checker_host = self._need23().checker_array()
+        return self._checker_host
+
+    @staticmethod
+    def _decode23(code: int) -> str:
+        return "".join("ACGT"[(code >> (2 * (22 - i))) & 3] for i in range(23))
+
+    def get_kmer_by_kid(self, kid: int) -> str:
+        ix = self._need23()                                                             # :718-724
+        if kid >= ix.n or kid < 0:
+            return ""
+        return self._decode23(int(self._checker()[kid]))
+
+    def get_kmer_info(self, kid: int):
+        ix = self._need23()                                                             # :744-755 -> (tf, kmer, rc)
+        if kid >= ix.n or kid < 0:
+            return (0, "", "")
+        kmer = self._decode23(int(self._checker()[kid]))
+        return (int(ix.tf_array()[kid]), kmer, self.get_reverse_complement_23mer(kmer))
+
+    def get_reverse_complement_13mer(self, kmer: str) -> str:
+        return _enc(kmer)[::-1].translate(_COMP).decode("latin-1")                      # :505-517
+
+    def get_reverse_complement_23mer(self, kmer: str) -> str:
+        b = _enc(kmer)                                                                  # :1288-1299: via the 2-bit code
+        if len(b) != 23:
+            return ""
+        code = 0
+        for c in b:
+            code = (code << 2) | {65: 0, 67: 1, 71: 2, 84: 3}.get(c, 0)
+        rc = _lib.lib().aix_selftest_revcomp(code, 23)
+        return self._decode23(rc)
+
+    # ---- metadata ----------------------------------------------------------------------------
+    def get_hash_size(self) -> int:
+        return self._ix23.n if self._ix23 is not None else 0                            # :846-851
+
+    def get_reads_size(self) -> int:
+        return self.reads_size
+
+    def get_index_info(self) -> str:
+        lines = [f"Mode: {'13-mer' if self._is_13mer_mode else '23-mer'}", f"Total k-mers: {self.n_kmers}"]
+        ix = self._ix13 if self._is_13mer_mode else self._ix23
+        if ix is not None:
+            i = ix.info
+            lines.append(f"HBM resident bytes: {i['device_bytes']} on device {i['device']}")
+        return "\n".join(lines)
+
+    def get_13mer_statistics(self) -> dict:
+        if not self._is_13mer_mode:                                                     # :1038-1068
+            return {}
+        tf = np.asarray(self._tf13_host)
+        nz = tf[tf != 0]
+        return {"total_kmers": TOTAL_13MERS, "non_zero_kmers": int(nz.shape[0]), "max_frequency": int(tf.max()),
+                "total_count": int(tf.sum(dtype=np.uint64))}
+
+    def get_23mer_statistics(self) -> str:
+        if self._is_13mer_mode:                                                         # :1301-1315
+            return "Not in 23-mer mode"
+        return (f"23-mer Index Statistics:\nTotal k-mers: {self.n_kmers}\nTotal reads: {self.n_reads}\n"
+                f"AIndex loaded: {'Yes' if self.aindex_loaded else 'No'}\nReads loaded: No\nHash map size: {self.get_hash_size()}\n")
+
+    # positions: get_positions dispatches on len 13/23 (:826-831); without a loaded position index the
+    # reference returns [] for 13-mers and aborts for absent 23-mers — [] here.
+    def get_positions(self, kmer: str) -> List[int]:
+        return []
+
+    get_positions_13mer = get_positions
+
+    def close(self):
+        for ix in (self._ix23, self._ix13):
+            if ix is not None:
+                ix.close()
+        self._ix23 = self._ix13 = None

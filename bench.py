@@ -1,0 +1,287 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X k-mer engine (contract: see the task statement).
+
+Default workload = BASELINE.json configs[2] ("23-mer emphf perfect-hash: build index on CPU, 100M random
+23-mer batch lookups on 1 MI355X, HBM GB/s vs roofline"): a ~5e7-key true-canonical 23-mer index of a
+synthetic 50 Mbp genome resident in HBM; one step = one batch of 100 M uniform-random 23-mer ASCII
+queries (already in HBM) through aix_tf_batch_ascii_dev. N > 1: every rank holds a replica of the index
+and its own 100 M queries (weak scaling, no data-path collective).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Other workloads (own measurements, same JSON shape): --workload count13 | count23 | lookup13.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_index23(genome_len, rank, world, device, cache_dir):
+    """Synthetic config-3 index, built without the oracle: keys/counts on the GPU, MPHF on the host CPU."""
+    import torch
+    from aindex_amd import builder, counting, engine, _lib
+    from aindex_amd.engine import Index
+    t0 = time.time()
+    g = engine.synth_genome_t(23, genome_len, device)
+    keys, counts = counting.count_distinct_t(g, 23, _lib.CANON_TRUE_RC)
+    counts32 = counts.to(torch.int32)
+    n = keys.numel()
+    torch.cuda.synchronize()
+    t1 = time.time()
+    pf_path = os.path.join(cache_dir, f"g23_{genome_len}.pf")
+    pf = None
+    if rank == 0:
+        if os.path.exists(pf_path):
+            pf = open(pf_path, "rb").read()
+            if int(np.frombuffer(pf[:8], dtype=np.uint64)[0]) != n:
+                pf = None
+        if pf is None:
+            pf = builder.build_pf_codes(keys.cpu().numpy().view(np.uint64), 23)
+            os.makedirs(cache_dir, exist_ok=True)
+            with open(pf_path + ".tmp", "wb") as f:
+                f.write(pf)
+            os.replace(pf_path + ".tmp", pf_path)
+    if world > 1:
+        import torch.distributed as dist
+        sz = torch.tensor([len(pf) if rank == 0 else 0], dtype=torch.int64, device=f"cuda:{device}")
+        dist.broadcast(sz, 0)
+        buf = torch.empty(int(sz.item()), dtype=torch.uint8, device=f"cuda:{device}")
+        if rank == 0:
+            buf.copy_(torch.frombuffer(bytearray(pf), dtype=torch.uint8))
+        dist.broadcast(buf, 0)
+        pf = buf.cpu().numpy().tobytes()
+    t2 = time.time()
+    ix = Index.build_23_codes_t(pf, keys, counts32, device)
+    torch.cuda.synchronize()
+    t3 = time.time()
+    log(f"[rank {rank}] index: n={n} keys/counts {t1 - t0:.1f}s, mphf {t2 - t1:.1f}s, scatter {t3 - t2:.2f}s, "
+        f"canonical_only={ix.canonical_only}, HBM {ix.info['device_bytes'] / 1e6:.0f} MB")
+    return ix, g, keys, counts32, pf
+
+
+def timed_steps(step_fn, steps, warmup, device):
+    """W warm-up steps, then exactly K steps bracketed by barrier + synchronize; per-launch HIP events on
+    torch's current stream (the stream the kernels are launched on)."""
+    import torch
+    from aindex_amd import dist as adist
+    for _ in range(warmup):
+        step_fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    adist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record()
+        step_fn()
+        b.record()
+    torch.cuda.synchronize()
+    adist.barrier()
+    t1 = time.perf_counter()
+    wall = adist.all_reduce_max_float(t1 - t0, device=f"cuda:{device}")
+    kern_ms = [a.elapsed_time(b) for a, b in evs]
+    return wall, float(np.mean(kern_ms)), kern_ms
+
+
+def cpu_baseline_lookup23(ix, pf, q_sample_np, gpu_sample, tmpdir):
+    """CPU path timed on this host on a bounded sample of the same queries against the same index:
+    the compiled reference itself (oracle/_ref/aindex_cpp, single-threaded batch get_tf_values through
+    pybind11, as the reference measures it) when present, plus our C restatement (1 thread / all cores)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    os.makedirs(tmpdir, exist_ok=True)
+    prefix = os.path.join(tmpdir, "bench23")
+    open(prefix + ".pf", "wb").write(pf)
+    ix.tf_array().tofile(prefix + ".tf.bin")
+    ix.checker_array().tofile(prefix + ".kmers.bin")
+    res = {}
+    ncores = os.cpu_count() or 1
+    orc = O.OracleIndex23.from_prefix(prefix)
+    s = q_sample_np.shape[0] // 23
+    t = time.perf_counter(); got = orc.tf_batch(q_sample_np, threads=1); dt = time.perf_counter() - t
+    assert np.array_equal(got, gpu_sample), "CPU port and GPU disagree on the sample"
+    res["port_1t"] = {"value": s / dt, "unit": "lookups/s", "cores": 1, "kind": "port", "sample": f"first {s} of the batch"}
+    t = time.perf_counter(); got = orc.tf_batch(q_sample_np, threads=ncores); dt = time.perf_counter() - t
+    assert np.array_equal(got, gpu_sample)
+    res["port_mt"] = {"value": s / dt, "unit": "lookups/s", "cores": ncores, "kind": "port", "sample": f"first {s} of the batch"}
+    del orc
+    ref_dir = os.path.join(ROOT, "oracle", "_ref")
+    try:
+        sys.path.insert(0, ref_dir)
+        import aindex_cpp
+        w = aindex_cpp.AindexWrapper()
+        devnull = os.open(os.devnull, os.O_WRONLY)
+        so, se = os.dup(1), os.dup(2)
+        os.dup2(devnull, 1); os.dup2(devnull, 2)              # the reference logs progress bars to stdout/stderr
+        try:
+            w.load_from_prefix_23mer(prefix)
+            sref = min(s, 1_000_000)
+            qs = [bytes(x).decode() for x in q_sample_np[: sref * 23].reshape(-1, 23)]
+            t = time.perf_counter(); got = w.get_tf_values(qs); dt = time.perf_counter() - t
+        finally:
+            os.dup2(so, 1); os.dup2(se, 2)
+        assert np.array_equal(np.array(got, dtype=np.uint32), gpu_sample[:sref]), "reference and GPU disagree on the sample"
+        res["reference"] = {"value": sref / dt, "unit": "lookups/s", "cores": 1, "kind": "reference",
+                            "sample": f"first {sref} of the batch via aindex_cpp.get_tf_values(list[str])"}
+    except Exception as e:  # reference build absent on this box
+        log(f"cpu_baseline: compiled reference not usable here ({type(e).__name__}: {e}); using the port")
+    for f in (".pf", ".tf.bin", ".kmers.bin"):
+        try:
+            os.remove(prefix + f)
+        except OSError:
+            pass
+    return res
+
+
+def load_pmc_traffic(workload):
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        d = json.load(open(p))
+        return d.get(workload)
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="lookup23", choices=["lookup23", "lookup13", "count13", "count23"])
+    ap.add_argument("--queries", type=int, default=100_000_000)
+    ap.add_argument("--genome", type=int, default=50_000_000)
+    ap.add_argument("--reads", type=int, default=10_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=2_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fastpath", action="store_true", help="force the reference's two-probe order")
+    a = ap.parse_args()
+
+    import torch
+    from aindex_amd import dist as adist, engine, _lib
+    rank, world, local = adist.init()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
+    torch.cuda.set_device(local)
+    dev = local
+    cache = os.path.join(ROOT, ".cache")
+    out = {"n_gpus": world, "steps": a.steps, "warmup": a.warmup, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "data": "synthetic"}
+
+    if a.workload == "lookup23":
+        ix, g, keys, counts, pf = build_index23(a.genome, rank, world, dev, cache)
+        if a.no_fastpath:
+            ix.set_canonical_fastpath(False)
+        q = engine.synth_kmers_t(7, a.queries, 23, dev, first=rank * a.queries)
+        res = torch.empty(a.queries, dtype=torch.int32, device=f"cuda:{dev}")
+        step = lambda: ix.tf_ascii_t(q, res)
+        wall, kern_ms, _ = timed_steps(step, a.steps, a.warmup, dev)
+        hits = int((res != 0).sum().item())
+        probes = 1.0 if (ix.canonical_only and not a.no_fastpath) else 2.0 - hits / a.queries   # misses probe both strands
+        # one MPHF evaluation E = 92 B, + 8 B checker per probe, + 4 B tf per hit, + 27 B streamed per query
+        bytes_per_query = 27.0 + probes * (92.0 + 8.0) + 4.0 * hits / a.queries
+        achieved = bytes_per_query * a.queries / (kern_ms * 1e-3) / 1e9
+        value = world * a.queries * a.steps / wall
+        out.update({"metric": "kmer_lookups_per_sec_23mer_batch", "value": value, "unit": "lookups/s",
+                    "ms_per_step": wall / a.steps * 1e3, "dtype": "u64",
+                    "config": {"workload": "configs[2]: 23-mer emphf MPHF batch lookup, uniform-random 23-mer ASCII queries resident in HBM",
+                               "queries_per_step_per_gpu": a.queries, "index_keys": ix.n, "genome_bp": a.genome,
+                               "query_seed": 7, "hit_fraction": hits / a.queries, "probes_per_query": probes,
+                               "canonical_fastpath": bool(ix.canonical_only and not a.no_fastpath), "parallelism": f"replica x{world}"},
+                    "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                 "traffic": None, "kernel": "k_lookup23_ascii", "kernel_ms": kern_ms,
+                                 "algorithmic_bytes_per_query": bytes_per_query}})
+        tr = load_pmc_traffic("lookup23")
+        if tr:
+            out["roofline"]["traffic"] = tr.get("bytes_per_launch")
+            out["roofline"]["traffic_source"] = tr.get("source")
+        if rank == 0 and world == 1 and not a.no_cpu_baseline:
+            s = min(a.cpu_sample, a.queries)
+            qs = q[: s * 23].cpu().numpy()
+            cb = cpu_baseline_lookup23(ix, pf, qs, res[:s].cpu().numpy().view(np.uint32), os.path.join(cache, "cpu"))
+            out["cpu_baseline"] = cb.get("reference", cb["port_1t"])
+            out["cpu_baseline_extra"] = {k: v for k, v in cb.items()}
+            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+
+    elif a.workload == "lookup13":
+        from aindex_amd.engine import Index
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from pf13 import pf13_path
+        ix = Index.open_13(pf13_path(), None, dev)
+        g = engine.synth_genome_t(13, 4_000_000, dev)
+        reads = engine.synth_reads_t(14, g, 1_000_000, 150, n_rate_ppm=1000)
+        tf = ix.count13_t(reads)
+        torch.cuda.synchronize()
+        ix.set_tf_13(tf.cpu().numpy().view(np.uint64))
+        q = engine.synth_kmers_t(15, a.queries, 13, dev, first=rank * a.queries)
+        res = torch.empty(a.queries, dtype=torch.int32, device=f"cuda:{dev}")
+        step = lambda: ix.tf_ascii_t(q, res)
+        wall, kern_ms, _ = timed_steps(step, a.steps, a.warmup, dev)
+        bpq = 13.0 + 4.0 + 8.0      # our layout: one 8-byte read of the code-ordered table (+ streamed query/result)
+        achieved = bpq * a.queries / (kern_ms * 1e-3) / 1e9
+        out.update({"metric": "kmer_lookups_per_sec_13mer_batch", "value": world * a.queries * a.steps / wall, "unit": "lookups/s",
+                    "ms_per_step": wall / a.steps * 1e3, "dtype": "u64",
+                    "config": {"workload": "13-mer dense table batch lookup, uniform-random 13-mers", "queries_per_step_per_gpu": a.queries},
+                    "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                 "traffic": None, "kernel": "k_lookup13_ascii", "kernel_ms": kern_ms}})
+
+    elif a.workload == "count13":
+        from aindex_amd.engine import Index
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from pf13 import pf13_path
+        ix = Index.open_13(pf13_path(), None, dev)
+        g = engine.synth_genome_t(13, 4_000_000, dev)
+        reads = engine.synth_reads_t(14, g, a.reads, 150, n_rate_ppm=1000, first_read=rank * a.reads)
+        tf = torch.empty(4 ** 13, dtype=torch.int64, device=f"cuda:{dev}")
+        def step():
+            ix.count13_t(reads, tf)
+            adist.all_reduce_sum_(tf)
+        wall, kern_ms, _ = timed_steps(step, a.steps, a.warmup, dev)
+        windows = a.reads * (150 - 12)
+        achieved = (a.reads * 151 + windows * 8.0) / (kern_ms * 1e-3) / 1e9
+        out.update({"metric": "reads_per_sec_13mer_count", "value": world * a.reads * a.steps / wall, "unit": "reads/s",
+                    "ms_per_step": wall / a.steps * 1e3, "dtype": "u64",
+                    "config": {"workload": "configs[1]: 13-mer dense 4^13 table count of 150 bp reads + all-reduce", "reads_per_step_per_gpu": a.reads},
+                    "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                 "traffic": None, "kernel": "k_count13 (+memset, scatter)", "kernel_ms": kern_ms}})
+
+    elif a.workload == "count23":
+        ix, g, keys, counts, pf = build_index23(a.genome, rank, world, dev, cache)
+        reads = engine.synth_reads_t(41, g, a.reads, 150, rc_half=True, n_rate_ppm=1000, first_read=rank * a.reads)
+        tf = torch.zeros(ix.n, dtype=torch.int32, device=f"cuda:{dev}")
+        def step():
+            tf.zero_()
+            ix.count23_fixed_t(reads, _lib.CANON_TRUE_RC, tf)
+            adist.all_reduce_sum_(tf)
+        wall, kern_ms, _ = timed_steps(step, a.steps, a.warmup, dev)
+        windows = a.reads * (150 - 22)
+        achieved = (a.reads * 151 + windows * (100.0 + 4.0 + 8.0)) / (kern_ms * 1e-3) / 1e9
+        out.update({"metric": "reads_per_sec_23mer_count_fixed_mphf", "value": world * a.reads * a.steps / wall, "unit": "reads/s",
+                    "ms_per_step": wall / a.steps * 1e3, "dtype": "u64",
+                    "config": {"workload": "configs[3]: 23-mer histogram against a fixed MPHF, 150 bp reads, + all-reduce(sum) of tf[]",
+                               "reads_per_step_per_gpu": a.reads, "index_keys": ix.n},
+                    "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                 "traffic": None, "kernel": "k_count23_fixed (+all-reduce)", "kernel_ms": kern_ms}})
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

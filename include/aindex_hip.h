@@ -93,6 +93,18 @@ int aix_index_get_tf(const aix_index_t* h, void* out, uint64_t out_bytes);
 /* copy the checker (stored 2-bit codes, u64[n]) out; get_kmer_by_kid / get_kmer_info (:718-755) */
 int aix_index_get_checker(const aix_index_t* h, uint64_t* out, uint64_t n);
 
+/* I1: replaces `compute_index <dat> <pf> <prefix> <threads> <mock>` (src/compute_index.cpp:34-72,
+ * index_hash_pp / worker_for_fill_index src/hash.cpp:671-723,779-881): for every key i,
+ * checker_out[mphf(key_i)] = 2-bit code, tf_out[mphf(key_i)] = counts[i] (counts NULL = mock, tf 0).
+ * keys = n*23 ASCII bytes (the first column of the .dat), outputs are the .kmers.bin / .tf.bin images.
+ * AIX_ERR_CONFLICT when two keys land in one slot or a slot >= n (reference: exit(12) / OOB write). */
+int aix_index_scatter(const void* pf_bytes, uint64_t pf_len, const char* keys, const uint32_t* counts, uint64_t n,
+                      int device, uint64_t* checker_out, uint32_t* tf_out);
+/* the same scatter from 2-bit codes already in HBM, keeping the result resident as a 23-mer handle */
+int aix_index_build_23_codes_dev(const void* pf_bytes, uint64_t pf_len, const uint64_t* d_codes,
+                                 const uint32_t* d_counts /* nullable */, uint64_t n, int device, void* stream,
+                                 aix_index_t** out);
+
 /* ------------------------------------------------------------------------------------------
  * Batch tf queries. `kmers` is N*k contiguous ASCII bytes (k = 23 or 13 per the handle).
  * 23-mer handle: AindexWrapper::get_tf_values / get_tf_values_23mer / get_tf_value_23mer
@@ -160,6 +172,12 @@ int aix_count13_dev(aix_index_t* h, const char* d_plain, uint64_t len, uint64_t*
 int aix_count23_fixed(aix_index_t* h, const char* buf, uint64_t len, int format, int canon_mode, uint32_t* tf_out);
 int aix_count23_fixed_dev(aix_index_t* h, const char* d_plain, uint64_t len, int canon_mode,
                           uint32_t* d_tf_out /* accumulated into, caller zeroes */, void* stream);
+/* K1 front end: replaces OptimizedKmerCounter's window loop (count_kmers.cpp:93-136,297-308) on a
+ * PLAIN buffer in HBM: d_codes[p] = canonical 2-bit code of the k-window starting at byte p
+ * (chars valid per count_kmers.cpp:71-88: ACGTU any case; canon_mode as above), or ~0 when the
+ * window contains any other byte. d_codes holds len-k+1 entries. Distinct k-mers and their counts are
+ * the sort + run-length of the valid entries (aindex_amd/counting.py). 1 <= k <= 32. */
+int aix_window_codes_dev(const char* d_plain, uint64_t len, int k, int canon_mode, uint64_t* d_codes, void* stream);
 /* Host-side record normalisation to PLAIN form (readers of count_kmers13.cpp:211-272 /
  * count_kmers.cpp:250-295): out must hold len+1 bytes; *out_len receives the normalised length.
  * fasta_mode: 0 = count_kmers13 rules, 1 = kmer_counter rules ('>' anywhere starts a record). */
@@ -184,6 +202,7 @@ int aix_synth_reads_dev(uint64_t seed, const char* d_genome, uint64_t genome_len
  * ------------------------------------------------------------------------------------------ */
 int aix_pf_build(const char* keys /* n*key_len bytes */, uint64_t n, uint32_t key_len, void** pf_out, uint64_t* pf_len);
 int aix_pf_build_ragged(const char* bytes, const uint64_t* offsets /* n+1 */, uint64_t n, void** pf_out, uint64_t* pf_len);
+int aix_pf_build_codes(const uint64_t* codes, uint64_t n, int k, void** pf_out, uint64_t* pf_len); /* keys = ASCII of 2-bit codes */
 int aix_pf_build_all_13mers(void** pf_out, uint64_t* pf_len);   /* generate_all_13mers + build_13mer_hash */
 void aix_free(void* p);
 

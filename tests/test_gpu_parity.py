@@ -1,0 +1,358 @@
+"""GPU parity: the HIP path (through the C ABI) against the oracle / golden fixtures. Bit-exact.
+
+Run on the MI355X box with `pytest -m gpu`. Nothing here reads /root/reference.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle_lib as O
+from aindex_amd import _lib, builder, synth
+from aindex_amd.engine import Index
+
+
+def load(gold, *p):
+    return json.load(open(os.path.join(gold, *p)))
+
+
+def flat(strs):
+    return np.frombuffer("".join(strs).encode(), dtype=np.uint8)
+
+
+# ------------------------------------------------------------------------------------------------
+# golden small23 index (built by the reference pipeline; stored set is NOT all-canonical)
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def ix23(small23_prefix):
+    ix = Index.open_23(small23_prefix + ".pf", small23_prefix + ".tf.bin", small23_prefix + ".kmers.bin")
+    yield ix
+    ix.close()
+
+
+@pytest.fixture(scope="module")
+def q23(gold):
+    return load(gold, "small23", "queries.json")
+
+
+def test_info(ix23, q23):
+    i = ix23.info
+    assert i["k"] == 23 and i["n"] == q23["n_kmers"] and i["bitpairs"] == 3 * i["hash_domain"]
+    assert i["canonical_only"] == 0        # kmer_counter's pseudo-canonical keys
+
+
+def test_q23_golden(ix23, q23):
+    qs = flat(q23["queries"])
+    assert ix23.tf_ascii(qs).tolist() == q23["tf"]
+    assert ix23.total_ascii(qs).tolist() == q23["total"]
+    f, r = ix23.both_ascii(qs)
+    assert [[int(a), int(b)] for a, b in zip(f, r)] == q23["both"]
+    assert ix23.hash_ascii(qs).tolist() == q23["hash"]
+    kid, strand = ix23.kid_strand_ascii(qs)
+    assert kid.tolist() == q23["kid"]
+    assert strand.tolist() == q23["strand"]
+
+
+def test_q23_ragged_matches_oracle(ix23, q23, small23_prefix):
+    orc = O.OracleIndex23.from_prefix(small23_prefix)
+    base = q23["queries"][:40] + q23["queries"][300:340]
+    items = []
+    for i, s in enumerate(base):
+        items += [s, s + "ACGT"[: i % 5], s[: 23 - (i % 4)], s + s, ""]
+    want = [orc.tf(x.encode()) for x in items]
+    assert ix23.tf_ragged(items).tolist() == want
+    assert any(want)
+
+
+def test_q23_coverage_golden(ix23, q23):
+    for cutoff in (0, 3):
+        cases = [c for c in q23["coverage"] if c["cutoff"] == cutoff]
+        got = ix23.coverage([c["seq"] for c in cases], cutoff)
+        for c, g in zip(cases, got):
+            assert g.tolist() == c["cov"]
+
+
+def test_tf_and_checker_roundtrip(ix23, small23_prefix):
+    assert np.array_equal(ix23.tf_array(), np.fromfile(small23_prefix + ".tf.bin", dtype=np.uint32))
+    assert np.array_equal(ix23.checker_array(), np.fromfile(small23_prefix + ".kmers.bin", dtype=np.uint64))
+
+
+def test_index_scatter_equals_compute_index(small23_prefix):
+    rows = [ln.split("\t") for ln in open(small23_prefix + ".dat").read().split("\n") if ln]
+    keys = flat([r[0] for r in rows])
+    tfs = np.array([int(r[1]) for r in rows], dtype=np.uint32)
+    pf = np.frombuffer(open(small23_prefix + ".pf", "rb").read(), dtype=np.uint8)
+    n = len(rows)
+    checker = np.empty(n, dtype=np.uint64)
+    tf = np.empty(n, dtype=np.uint32)
+    vp = _lib.vp
+    _lib.check(_lib.lib().aix_index_scatter(pf.ctypes.data_as(vp), pf.shape[0], keys.ctypes.data_as(vp), tfs.ctypes.data_as(vp), n, 0,
+                                            checker.ctypes.data_as(vp), tf.ctypes.data_as(vp)))
+    assert np.array_equal(checker, np.fromfile(small23_prefix + ".kmers.bin", dtype=np.uint64))
+    assert np.array_equal(tf, np.fromfile(small23_prefix + ".tf.bin", dtype=np.uint32))
+    # a key outside the MPHF set collides with a stored one
+    bad = keys.copy()
+    bad[:23] = np.frombuffer(b"ACGTTGCATTTTACGATCGGCAT", dtype=np.uint8)
+    st = _lib.lib().aix_index_scatter(pf.ctypes.data_as(vp), pf.shape[0], bad.ctypes.data_as(vp), tfs.ctypes.data_as(vp), n, 0,
+                                      checker.ctypes.data_as(vp), tf.ctypes.data_as(vp))
+    assert st in (0, -12)   # lands on a free slot only if it happens to hash onto its victim's slot
+
+
+def test_count23_fixed_refx86_equals_pipeline(ix23, gold, small23_prefix):
+    fa = open(os.path.join(gold, "small23", "reads.fa"), "rb").read()
+    tf = ix23.count23_fixed(fa, _lib.FMT_FASTA, _lib.CANON_REF_X86)
+    assert np.array_equal(tf, np.fromfile(small23_prefix + ".tf.bin", dtype=np.uint32))
+    orc = O.OracleIndex23.from_prefix(small23_prefix)
+    for mode in (0, 2):
+        assert np.array_equal(ix23.count23_fixed(fa, _lib.FMT_FASTA, mode), orc.count23_fixed(fa, True, mode))
+
+
+# ------------------------------------------------------------------------------------------------
+# synthetic true-canonical index (canonical fast path), mid size, vs oracle
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def canon_case(tmp_path_factory):
+    d = tmp_path_factory.mktemp("canon")
+    g = synth.genome_codes(23, 300_000)
+    keys, counts = synth.canonical_distinct(g, 23)
+    pf = builder.build_pf_codes(keys, 23)
+    prefix = str(d / "canon")
+    open(prefix + ".pf", "wb").write(pf)
+    m = O.OracleMphf(prefix + ".pf")
+    ascii_keys = synth.decode_kmers(keys, 23)
+    # product-side scatter makes the files; the oracle then loads them like the reference would
+    n = keys.shape[0]
+    checker = np.empty(n, dtype=np.uint64)
+    tf = np.empty(n, dtype=np.uint32)
+    vp = _lib.vp
+    pfa = np.frombuffer(pf, dtype=np.uint8)
+    flatk = np.ascontiguousarray(ascii_keys).reshape(-1)
+    _lib.check(_lib.lib().aix_index_scatter(pfa.ctypes.data_as(vp), pfa.shape[0], flatk.ctypes.data_as(vp), counts.ctypes.data_as(vp), n, 0,
+                                            checker.ctypes.data_as(vp), tf.ctypes.data_as(vp)))
+    rc, ochecker, otf = O.index_scatter(m, flatk, counts)
+    assert rc == 0 and np.array_equal(checker, ochecker) and np.array_equal(tf, otf)
+    checker.tofile(prefix + ".kmers.bin")
+    tf.tofile(prefix + ".tf.bin")
+    ix = Index.open_23(prefix + ".pf", prefix + ".tf.bin", prefix + ".kmers.bin")
+    orc = O.OracleIndex23.from_prefix(prefix)
+    yield {"ix": ix, "orc": orc, "genome": g, "keys": keys, "counts": counts, "prefix": prefix}
+    ix.close()
+
+
+def mixed_queries(genome_codes, n, seed):
+    """50 % genome windows on a random strand, 50 % uniform random 23-mers, a sprinkle of N / lower-case."""
+    w = synth.rolling_codes(genome_codes, 23)
+    pick = (synth.sm64(seed, np.arange(n // 2, dtype=np.uint64)) % np.uint64(w.shape[0])).astype(np.int64)
+    codes = w[pick]
+    flip = (synth.sm64(seed + 1, np.arange(n // 2, dtype=np.uint64)) & np.uint64(1)).astype(bool)
+    codes = np.where(flip, synth.revcomp_codes(codes, 23), codes)
+    q = np.concatenate([synth.decode_kmers(codes, 23), synth.random_kmers_ascii(seed + 2, n - n // 2, 23)])
+    q = q.copy()
+    idx = np.arange(0, q.shape[0], 97)
+    q[idx, (idx * 7) % 23] = ord("N")
+    idx = np.arange(5, q.shape[0], 131)
+    q[idx] |= 0x20                      # lower-case letters
+    return q
+
+
+def test_canonical_index_flag_and_queries(canon_case):
+    ix, orc = canon_case["ix"], canon_case["orc"]
+    assert ix.canonical_only
+    q = mixed_queries(canon_case["genome"], 200_000, 8)
+    want = orc.tf_batch(q, threads=8)
+    assert (want != 0).sum() > 50_000
+    got_fast = ix.tf_ascii(q)
+    assert np.array_equal(got_fast, want)
+    ix.set_canonical_fastpath(False)
+    try:
+        assert np.array_equal(ix.tf_ascii(q), want)
+        tot_slow = ix.total_ascii(q)
+        kid_slow, strand_slow = ix.kid_strand_ascii(q)
+    finally:
+        ix.set_canonical_fastpath(True)
+    assert np.array_equal(ix.total_ascii(q), tot_slow)
+    kid, strand = ix.kid_strand_ascii(q)
+    assert np.array_equal(kid, kid_slow) and np.array_equal(strand, strand_slow)
+    sub = q[:3000]
+    assert tot_slow[:3000].tolist() == [orc.total(bytes(s)) for s in sub]
+    assert strand[:3000].tolist() == [orc.strand(bytes(s)) for s in sub]
+    assert kid[:3000].tolist() == [orc.kid(bytes(s)) for s in sub]
+    assert np.array_equal(ix.hash_ascii(q), orc.hash_batch(q))
+
+
+def test_codes_api_equals_ascii(canon_case):
+    ix = canon_case["ix"]
+    q = synth.decode_kmers(synth.rolling_codes(canon_case["genome"][:50_000], 23), 23)
+    codes = synth.encode_kmers(q)
+    a = ix.tf_ascii(q)
+    assert np.array_equal(ix.tf_codes(codes), a)
+    ix.set_canonical_fastpath(False)
+    try:
+        assert np.array_equal(ix.tf_codes(codes), a)
+    finally:
+        ix.set_canonical_fastpath(True)
+    assert (a != 0).all()
+
+
+def test_coverage_vs_oracle(canon_case):
+    ix, orc, g = canon_case["ix"], canon_case["orc"], canon_case["genome"]
+    asc = synth.genome_ascii(23, 300_000)
+    seqs = [bytes(asc[1000:6000]), bytes(asc[20000:20030]), b"ACGT", b"", bytes(asc[7000:7023]), bytes(asc[9000:12000]).lower(),
+            bytes(asc[40000:41000]).replace(b"A", b"N", 3)]
+    for cutoff in (0, 2):
+        got = ix.coverage(seqs, cutoff)
+        for s, gq in zip(seqs, got):
+            assert np.array_equal(gq, orc.coverage(s, cutoff))
+
+
+def test_count23_true_rc_vs_oracle_and_genome_multiplicity(canon_case):
+    ix, orc = canon_case["ix"], canon_case["orc"]
+    asc = synth.genome_ascii(23, 300_000)
+    reads = synth.reads_plain(41, asc, 3000, 150, rc_fraction_half=True, n_rate_ppm=1000).tobytes()
+    got = ix.count23_fixed(reads, _lib.FMT_PLAIN, _lib.CANON_TRUE_RC)
+    assert np.array_equal(got, orc.count23_fixed(reads, False, 2))
+    assert got.sum() > 300_000
+    # the whole genome as one read reproduces the stored multiplicities (tf = genome multiplicity)
+    whole = ix.count23_fixed(bytes(asc) + b"\n", _lib.FMT_PLAIN, _lib.CANON_TRUE_RC)
+    assert np.array_equal(whole, ix.tf_array())
+
+
+# ------------------------------------------------------------------------------------------------
+# 13-mer mode
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def ix13():
+    from pf13 import pf13_path
+    ix = Index.open_13(pf13_path(), None)
+    yield ix
+    ix.close()
+
+
+NAMES13 = ["refdata_test.fasta", "refdata_test_se.fastq", "refdata_test_reads.txt", "refdata_test_unknown.txt",
+           "refdata_test_R1.fastq", "synth.fa", "synth.fq", "synth.txt"]
+
+
+@pytest.mark.parametrize("name", NAMES13)
+def test_count13_golden(ix13, gold, name):
+    z = np.load(os.path.join(gold, "count13", "expected.npz"))
+    buf = open(os.path.join(gold, "count13", name), "rb").read()
+    counts = ix13.count13(buf)
+    nz = np.nonzero(counts)[0]
+    assert np.array_equal(nz.astype(np.uint64), z[name + ".idx"])
+    assert np.array_equal(counts[nz], z[name + ".cnt"])
+
+
+def test_q13_golden(ix13, gold):
+    z = np.load(os.path.join(gold, "count13", "expected.npz"))
+    tf = np.zeros(4 ** 13, dtype=np.uint64)
+    tf[z["synth.fa.idx"].astype(np.int64)] = z["synth.fa.cnt"]
+    tf[int(z["synth.fa.idx"][0])] += 1 << 32          # exercises the u64 -> u32 truncation of get_tf_values
+    ix13.set_tf_13(tf)
+    q = load(gold, "q13.json")
+    want = list(q["tf"])
+    got = ix13.tf_ragged(q["queries"]).tolist()
+    assert got == want
+    valid = flat(q["valid"])
+    tot = ix13.total_ascii(valid)
+    f, r = ix13.both_ascii(valid)
+    hot = int(tf[int(z["synth.fa.idx"][0])])
+    exp_tot = np.array(q["total"], dtype=np.uint64)
+    exp_both = np.array(q["both"], dtype=np.uint64)
+    # undo the 2^32 bump for the comparison with the golden (which was taken without it)
+    bump_f = (f >= (1 << 32))
+    bump_r = (r >= (1 << 32))
+    assert np.array_equal(f - bump_f.astype(np.uint64) * np.uint64(1 << 32), exp_both[:, 0])
+    assert np.array_equal(r - bump_r.astype(np.uint64) * np.uint64(1 << 32), exp_both[:, 1])
+    assert np.array_equal(tot, f + r)
+    assert np.array_equal(ix13.tf_array(), tf)
+    for c in q["coverage"]:
+        assert ix13.coverage([c["seq"]], c["cutoff"])[0].tolist() == c["cov"]
+    assert hot >= (1 << 32)
+
+
+def test_13mer_vs_oracle_synthetic(ix13):
+    from pf13 import pf13_path
+    asc = synth.genome_ascii(13, 400_000)
+    reads = synth.reads_plain(14, asc, 20_000, 150, n_rate_ppm=1000).tobytes()
+    m = O.OracleMphf(pf13_path())
+    want = O.count13(m, reads, 0, threads=8)
+    got = ix13.count13(reads, _lib.FMT_PLAIN)
+    assert np.array_equal(got, want)
+    assert int(got.sum()) > 2_500_000
+    ix13.set_tf_13(got)
+    orc = O.OracleIndex13(pf13_path(), got)
+    q = np.concatenate([synth.decode_kmers(synth.rolling_codes(synth.genome_codes(13, 400_000)[:100_000], 13), 13),
+                        synth.random_kmers_ascii(15, 100_000, 13)]).copy()
+    q[::50, 3] = ord("N")
+    q[7::61] |= 0x20
+    assert np.array_equal(ix13.tf_ascii(q), orc.tf_batch(q, threads=8))
+    sub = q[:4000]
+    tot = ix13.total_ascii(sub)
+    assert tot.tolist() == [orc.total(bytes(s)) for s in sub]
+    f, r = ix13.both_ascii(sub)
+    assert [(int(a), int(b)) for a, b in zip(f, r)] == [orc.both(bytes(s)) for s in sub]
+
+
+# ------------------------------------------------------------------------------------------------
+# device generators == numpy mirror; HBM-resident entry points == host entry points
+# ------------------------------------------------------------------------------------------------
+def test_synth_generators_match_numpy():
+    import torch
+    from aindex_amd import engine
+    g = engine.synth_genome_t(23, 100_003)
+    assert np.array_equal(g.cpu().numpy(), synth.genome_ascii(23, 100_003))
+    for k in (23, 13):
+        q = engine.synth_kmers_t(7, 5000, k, first=11)
+        assert np.array_equal(q.cpu().numpy().reshape(-1, k), synth.random_kmers_ascii(7, 5000, k, start=11))
+    r = engine.synth_reads_t(41, g, 2000, 150, rc_half=True, n_rate_ppm=1000, first_read=5)
+    want = synth.reads_plain(41, synth.genome_ascii(23, 100_003), 2000, 150, rc_fraction_half=True, n_rate_ppm=1000, first_read=5)
+    assert np.array_equal(r.cpu().numpy(), want)
+    torch.cuda.synchronize()
+
+
+def test_device_entry_points(canon_case):
+    import torch
+    from aindex_amd import engine
+    ix = canon_case["ix"]
+    q = engine.synth_kmers_t(7, 100_000, 23)
+    out = ix.tf_ascii_t(q)
+    torch.cuda.synchronize()
+    host = ix.tf_ascii(q.cpu().numpy())
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), host)
+    # unaligned device views must work too (window loader never reads outside the view)
+    buf = torch.empty(23 * 1000 + 64, dtype=torch.uint8, device="cuda")
+    for off in (1, 2, 3):
+        v = buf[off: off + 23 * 1000]
+        v.copy_(q[: 23 * 1000])
+        o = ix.tf_ascii_t(v)
+        torch.cuda.synchronize()
+        assert np.array_equal(o.cpu().numpy().view(np.uint32), host[:1000])
+
+
+# ------------------------------------------------------------------------------------------------
+# size-independent properties at a larger size (no oracle in the loop)
+# ------------------------------------------------------------------------------------------------
+def test_properties_at_scale(canon_case):
+    import torch
+    from aindex_amd import engine
+    ix = canon_case["ix"]
+    n = 5_000_000
+    q = engine.synth_kmers_t(70, n, 23)
+    a = ix.tf_ascii_t(q).cpu().numpy().view(np.uint32)
+    ix.set_canonical_fastpath(False)
+    try:
+        b = ix.tf_ascii_t(q).cpu().numpy().view(np.uint32)
+    finally:
+        ix.set_canonical_fastpath(True)
+    assert np.array_equal(a, b)                       # one-probe fast path == reference two-probe order
+    assert (a != 0).sum() == 0 or (a != 0).mean() < 1e-3   # uniform random 23-mers essentially never hit
+    # every stored key and its reverse complement return the stored tf
+    keys, counts = canon_case["keys"], canon_case["counts"]
+    tf_fwd = ix.tf_codes(keys)
+    tf_rc = ix.tf_codes(synth.revcomp_codes(keys, 23))
+    assert np.array_equal(tf_fwd, counts) and np.array_equal(tf_rc, counts)
+    tot = ix.total_ascii(synth.decode_kmers(keys[:100_000], 23))
+    assert np.array_equal(tot, 2 * counts[:100_000].astype(np.uint64))
