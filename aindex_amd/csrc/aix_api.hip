@@ -545,6 +545,13 @@ extern "C" int aix_window_codes_dev(const char* d_plain, uint64_t len, int k, in
     return AIX_OK;
 }
 
+extern "C" int aix_bench_gather_dev(const void* d_table, uint64_t n_elems, int elem_bytes, int unroll, uint64_t n_access, uint64_t seed, uint64_t* d_sink,
+                                    void* stream) {
+    if (!d_table || !d_sink || n_elems == 0 || (n_elems >> 32)) return AIX_ERR_ARG;
+    HIPCHK(launch_gather((const uint8_t*)d_table, n_elems, elem_bytes, unroll, n_access, seed, d_sink, (hipStream_t)stream));
+    return AIX_OK;
+}
+
 extern "C" int aix_synth_genome_dev(uint64_t seed, uint64_t length, char* d_out, void* stream) {
     if (length && !d_out) return AIX_ERR_ARG;
     HIPCHK(launch_synth_genome(seed, length, (uint8_t*)d_out, (hipStream_t)stream));

@@ -51,6 +51,8 @@ hipError_t launch_count23_fixed(const IndexDev& ix, const uint8_t* buf, uint64_t
 
 hipError_t launch_window_codes(const uint8_t* buf, uint64_t len, int k, int canon_mode, uint64_t* out /* [len-k+1] */, hipStream_t s);
 
+hipError_t launch_gather(const uint8_t* table, uint64_t n_elems, int elem_bytes, int unroll, uint64_t n_access, uint64_t seed, uint64_t* sink, hipStream_t s);
+
 // synthetic generators
 hipError_t launch_synth_genome(uint64_t seed, uint64_t length, uint8_t* out, hipStream_t s);
 hipError_t launch_synth_kmers(uint64_t seed, uint64_t first, uint64_t N, int k, uint8_t* out, hipStream_t s);

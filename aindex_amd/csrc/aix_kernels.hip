@@ -543,6 +543,33 @@ __global__ void __launch_bounds__(kBlock) k_synth_reads(uint64_t seed, const uin
 }
 
 // ---------------------------------------------------------------------------------------------
+// random-gather roofline probe: uniform-random ELEM-byte reads over a large table,
+// UNROLL independent reads in flight per lane. The denominator the lookup kernels are judged against.
+// ---------------------------------------------------------------------------------------------
+template <int ELEM, int UNROLL>
+__global__ void __launch_bounds__(kBlock) k_gather(const uint8_t* __restrict__ table, uint64_t n_elems, uint64_t n_access, uint64_t seed, uint64_t* __restrict__ sink) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock * UNROLL;
+    uint64_t acc = 0;
+    for (uint64_t i = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * UNROLL; i < n_access; i += stride) {
+        uint64_t idx[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) idx[u] = ((sm64(seed, i + u) >> 32) * n_elems) >> 32;
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            if (ELEM == 16) {
+                const BvRec r = ((const BvRec*)table)[idx[u]];
+                acc += r.word ^ r.prefix;
+            } else if (ELEM == 8) {
+                acc += ((const uint64_t*)table)[idx[u]];
+            } else {
+                acc += ((const uint32_t*)table)[idx[u]];
+            }
+        }
+    }
+    if (acc == 0x1234567887654321ULL) sink[0] = acc;   // keeps the loads alive; practically never taken
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
 #define AIX_LAUNCH(kern, work, stream, ...)                                          \
@@ -628,6 +655,14 @@ hipError_t launch_window_codes(const uint8_t* buf, uint64_t len, int k, int cano
     if (k == 23) AIX_LAUNCH(k_window_codes<23>, len - k + 1, s, buf, len, k, canon_mode, out);
     if (k == 13) AIX_LAUNCH(k_window_codes<13>, len - k + 1, s, buf, len, k, canon_mode, out);
     AIX_LAUNCH(k_window_codes<0>, len - k + 1, s, buf, len, k, canon_mode, out);
+}
+hipError_t launch_gather(const uint8_t* table, uint64_t n_elems, int elem, int unroll, uint64_t n_access, uint64_t seed, uint64_t* sink, hipStream_t s) {
+    if (n_access == 0) return hipSuccess;
+    const uint64_t work = (n_access + unroll - 1) / unroll;
+#define G(E, U) if (elem == E && unroll == U) AIX_LAUNCH((k_gather<E, U>), work, s, table, n_elems, n_access, seed, sink)
+    G(16, 1); G(16, 4); G(8, 1); G(8, 4); G(4, 1); G(4, 4);
+#undef G
+    return hipErrorInvalidValue;
 }
 hipError_t launch_synth_genome(uint64_t seed, uint64_t length, uint8_t* out, hipStream_t s) {
     if (length == 0) return hipSuccess;

@@ -160,7 +160,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="lookup23", choices=["lookup23", "lookup13", "count13", "count23"])
+    ap.add_argument("--workload", default="lookup23", choices=["lookup23", "lookup13", "count13", "count23", "gather"])
+    ap.add_argument("--table-mib", type=int, default=4096)
+    ap.add_argument("--elem", type=int, default=16)
+    ap.add_argument("--unroll", type=int, default=1)
     ap.add_argument("--queries", type=int, default=100_000_000)
     ap.add_argument("--genome", type=int, default=50_000_000)
     ap.add_argument("--reads", type=int, default=10_000_000)
@@ -174,6 +177,8 @@ def main():
     rank, world, local = adist.init()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
+    if os.environ.get("AIX_BENCH_ONE_DEVICE"):      # rehearsal of the N>1 path on a 1-GPU box (gloo backend)
+        local = 0
     torch.cuda.set_device(local)
     dev = local
     cache = os.path.join(ROOT, ".cache")
@@ -274,6 +279,21 @@ def main():
                                "reads_per_step_per_gpu": a.reads, "index_keys": ix.n},
                     "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                  "traffic": None, "kernel": "k_count23_fixed (+all-reduce)", "kernel_ms": kern_ms}})
+
+    elif a.workload == "gather":
+        from aindex_amd._lib import lib, check, vp
+        nel = a.table_mib * (1 << 20) // a.elem
+        table = torch.empty(nel * a.elem // 8, dtype=torch.int64, device=f"cuda:{dev}")
+        table.random_(0, 1 << 40)
+        sink = torch.zeros(8, dtype=torch.int64, device=f"cuda:{dev}")
+        sp = vp(torch.cuda.current_stream().cuda_stream)
+        step = lambda: check(lib().aix_bench_gather_dev(vp(table.data_ptr()), nel, a.elem, a.unroll, a.queries, 99, vp(sink.data_ptr()), sp))
+        wall, kern_ms, _ = timed_steps(step, a.steps, a.warmup, dev)
+        rate = a.queries / (kern_ms * 1e-3)
+        out.update({"metric": "random_gather_accesses_per_sec", "value": rate, "unit": "accesses/s", "ms_per_step": wall / a.steps * 1e3, "dtype": f"u{a.elem * 8}",
+                    "config": {"workload": f"uniform-random {a.elem}-byte gather over {a.table_mib} MiB, {a.unroll} in flight per lane", "accesses": a.queries},
+                    "roofline": {"bound": "hbm", "achieved": rate * 64 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s (64 B per access)", "frac": rate * 64 / 1e9 / HBM_PEAK_GBS,
+                                 "traffic": None, "kernel": "k_gather", "kernel_ms": kern_ms}})
 
     if rank == 0:
         print(json.dumps(out), flush=True)

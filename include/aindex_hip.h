@@ -206,6 +206,11 @@ int aix_pf_build_codes(const uint64_t* codes, uint64_t n, int k, void** pf_out, 
 int aix_pf_build_all_13mers(void** pf_out, uint64_t* pf_len);   /* generate_all_13mers + build_13mer_hash */
 void aix_free(void* p);
 
+/* Roofline probe: n_access uniform-random reads of elem_bytes (4, 8 or 16) over a table
+ * of n_elems elements in HBM, `unroll` (1 or 4) independent reads in flight per lane. Measurement aid only. */
+int aix_bench_gather_dev(const void* d_table, uint64_t n_elems, int elem_bytes, int unroll, uint64_t n_access,
+                         uint64_t seed, uint64_t* d_sink, void* stream);
+
 /* self-test hook for the CPU test-suite: the exact-modulo used by the kernels, run on the host */
 uint64_t aix_selftest_mod(uint64_t h, uint64_t d);
 uint64_t aix_selftest_revcomp(uint64_t code, int k);
