@@ -60,6 +60,8 @@ struct aix_index {
     uint64_t* tf13_code = nullptr;
     uint32_t* perm13 = nullptr;
     unsigned long long* scratch13 = nullptr;   // code-ordered count table, lazily allocated
+    void* work13 = nullptr;                    // partition workspace of the atomic-free counter (grow-only)
+    uint64_t work13_bytes = 0;
     uint64_t device_bytes = 0;
     bool canonical_only = false;
     bool canonical_fastpath = true;
@@ -187,6 +189,7 @@ static void destroy(aix_index* h) {
     if (h->tf13_code) (void)hipFree(h->tf13_code);
     if (h->perm13) (void)hipFree(h->perm13);
     if (h->scratch13) (void)hipFree(h->scratch13);
+    if (h->work13) (void)hipFree(h->work13);
     delete h;
 }
 
@@ -516,14 +519,30 @@ extern "C" int aix_count13_dev(aix_index_t* h, const char* d_plain, uint64_t len
     if (h->k != 13) return AIX_ERR_MODE;
     DevGuard g(h->device);
     std::lock_guard<std::mutex> lk(h->count_mutex);
-    if (!h->scratch13) {
-        HIPCHK(hipMalloc((void**)&h->scratch13, 8 * AIX_TOTAL_13MERS));
-        h->device_bytes += 8 * AIX_TOTAL_13MERS;
-    }
     hipStream_t s = (hipStream_t)stream;
-    HIPCHK(hipMemsetAsync(h->scratch13, 0, 8 * AIX_TOTAL_13MERS, s));
+    static const bool use_atomics = getenv("AIX_COUNT13_ATOMICS") != nullptr;      // A/B switch for measurements
+    if (use_atomics || len >= (1ull << 32)) {
+        if (!h->scratch13) {
+            HIPCHK(hipMalloc((void**)&h->scratch13, 8 * AIX_TOTAL_13MERS));
+            h->device_bytes += 8 * AIX_TOTAL_13MERS;
+        }
+        // 1.4e9-window launches and beyond: scattered u64 memory-side atomics (slower, no size limit)
+        HIPCHK(hipMemsetAsync(h->scratch13, 0, 8 * AIX_TOTAL_13MERS, s));
+        HIPCHK(launch_count13_plain((const uint8_t*)d_plain, len, h->scratch13, s));
+    } else {
+        const uint64_t need = count13_workspace_bytes(len);
+        if (need > h->work13_bytes) {
+            HIPCHK(hipStreamSynchronize(s));
+            if (h->work13) { (void)hipFree(h->work13); h->device_bytes -= h->work13_bytes; h->work13 = nullptr; h->work13_bytes = 0; }
+            HIPCHK(hipMalloc(&h->work13, need));
+            h->work13_bytes = need;
+            h->device_bytes += need;
+        }
+        HIPCHK(hipMemsetAsync(d_tf_out, 0, 8 * AIX_TOTAL_13MERS, s));
+        HIPCHK(launch_count13_partitioned((const uint8_t*)d_plain, len, h->work13, nullptr, h->perm13, d_tf_out, s));   // fused permutation
+        return AIX_OK;
+    }
     HIPCHK(hipMemsetAsync(d_tf_out, 0, 8 * AIX_TOTAL_13MERS, s));
-    HIPCHK(launch_count13_plain((const uint8_t*)d_plain, len, h->scratch13, s));
     HIPCHK(launch_scatter13_to_mphf(h->perm13, h->scratch13, d_tf_out, s));
     return AIX_OK;
 }

@@ -160,7 +160,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="lookup23", choices=["lookup23", "lookup13", "count13", "count23", "gather"])
+    ap.add_argument("--workload", default="lookup23", choices=["lookup23", "lookup13", "count13", "count23", "gather", "coverage23"])
+    ap.add_argument("--seqs", type=int, default=100_000)
+    ap.add_argument("--seq-len", type=int, default=10_000)
     ap.add_argument("--table-mib", type=int, default=4096)
     ap.add_argument("--elem", type=int, default=16)
     ap.add_argument("--unroll", type=int, default=1)
@@ -279,6 +281,25 @@ def main():
                                "reads_per_step_per_gpu": a.reads, "index_keys": ix.n},
                     "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                  "traffic": None, "kernel": "k_count23_fixed (+all-reduce)", "kernel_ms": kern_ms}})
+
+    elif a.workload == "coverage23":
+        ix, g, keys, counts, pf = build_index23(a.genome, rank, world, dev, cache)
+        L = a.seq_len
+        seqs = engine.synth_reads_t(51, g, a.seqs, L, rc_half=True, n_rate_ppm=1000, first_read=rank * a.seqs)   # records of L bases + '\n'
+        offs = torch.arange(0, (a.seqs + 1) * (L + 1), L + 1, dtype=torch.int64, device=f"cuda:{dev}")
+        per = (L + 1) - 23 + 1
+        ooffs = torch.arange(0, (a.seqs + 1) * per, per, dtype=torch.int64, device=f"cuda:{dev}")
+        outp = torch.zeros(a.seqs * per, dtype=torch.int32, device=f"cuda:{dev}")
+        step = lambda: ix.coverage_t(seqs, offs, ooffs, a.seqs * per, 0, outp)
+        wall, kern_ms, _ = timed_steps(step, a.steps, a.warmup, dev)
+        positions = a.seqs * per
+        achieved = positions * (1.0 + 100.0 + 4.0 + 4.0) / (kern_ms * 1e-3) / 1e9
+        out.update({"metric": "sequences_per_sec_coverage_23mer", "value": world * a.seqs * a.steps / wall, "unit": "sequences/s",
+                    "ms_per_step": wall / a.steps * 1e3, "dtype": "u64",
+                    "config": {"workload": f"configs[4]: per-position tf profile (k=23) of {L} bp sequences drawn from the indexed genome (50 % rc, 0.1 % N)",
+                               "sequences_per_step_per_gpu": a.seqs, "positions_per_step": positions, "nonzero_fraction": float((outp != 0).float().mean().item())},
+                    "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                 "traffic": None, "kernel": "k_coverage", "kernel_ms": kern_ms, "positions_per_sec": positions / (kern_ms * 1e-3)}})
 
     elif a.workload == "gather":
         from aindex_amd._lib import lib, check, vp
