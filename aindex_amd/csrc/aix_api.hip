@@ -852,3 +852,49 @@ extern "C" int aix_count23_fixed(aix_index_t* h, const char* buf, uint64_t len, 
     HIPCHK(hipMemcpy(tf_out, dout.p, 4 * h->n, hipMemcpyDeviceToHost));
     return AIX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// A1/A2: positions index
+// ---------------------------------------------------------------------------------------------
+// first window the reference's single worker looks at (hash.cpp:973-986): the start is pushed past any
+// '\n', '~' or '?' found in the first k bytes, repeatedly
+static uint64_t a2_start(const char* c, uint64_t len) {
+    const uint64_t k = 23;
+    if (len < k) return 0;
+    uint64_t start = 0;
+    const uint64_t end = len;
+    while (start < end - k + 1) {
+        bool found = false;
+        for (uint64_t i = start; i < start + k; ++i)
+            if (c[i] == '\n' || c[i] == '~' || c[i] == '?') { start = i + 1; found = true; break; }
+        if (!found) break;
+    }
+    return start;
+}
+
+extern "C" int aix_positions_fill(aix_index_t* h, const char* reads, uint64_t len, uint64_t* indices_out, uint64_t* positions_out, uint64_t positions_cap,
+                                  uint64_t* total_out) {
+    if (!h || !indices_out || (len && !reads)) return AIX_ERR_ARG;
+    if (h->k != 23) return AIX_ERR_MODE;
+    if (len >> 32) return AIX_ERR_UNSUPPORTED;
+    DevGuard g(h->device);
+    const uint64_t n = h->n;
+    DevBuf dind;
+    HIPCHK(dind.alloc(8 * (n + 1)));
+    if (n) HIPCHK(positions_indices(h->dev(), (uint64_t*)dind.p, 0));
+    else HIPCHK(hipMemset(dind.p, 0, 8));
+    HIPCHK(hipMemcpy(indices_out, dind.p, 8 * (n + 1), hipMemcpyDeviceToHost));
+    const uint64_t total = indices_out[n];
+    if (total_out) *total_out = total;
+    if (!positions_out) return AIX_OK;
+    if (positions_cap < total) return AIX_ERR_ARG;
+    if (total == 0) return AIX_OK;
+    DevBuf dreads, dpos;
+    HIPCHK(dreads.alloc(len + 8));
+    HIPCHK(dpos.alloc(8 * total));
+    if (len) HIPCHK(hipMemcpy(dreads.p, reads, len, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(dpos.p, 0, 8 * total));
+    HIPCHK(positions_fill(h->dev(), (const uint8_t*)dreads.p, len, a2_start(reads, len), (const uint64_t*)dind.p, (uint64_t*)dpos.p, 0));
+    HIPCHK(hipMemcpy(positions_out, dpos.p, 8 * total, hipMemcpyDeviceToHost));
+    return AIX_OK;
+}

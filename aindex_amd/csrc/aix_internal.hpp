@@ -57,6 +57,11 @@ hipError_t launch_window_codes(const uint8_t* buf, uint64_t len, int k, int cano
 
 hipError_t launch_gather(const uint8_t* table, uint64_t n_elems, int elem_bytes, int unroll, uint64_t n_access, uint64_t seed, uint64_t* sink, hipStream_t s);
 
+// positions index (aix_positions.hip)
+hipError_t positions_indices(const IndexDev& ix, uint64_t* d_indices /* n+1 */, hipStream_t s);
+hipError_t positions_fill(const IndexDev& ix, const uint8_t* d_reads, uint64_t len, uint64_t start, const uint64_t* d_indices, uint64_t* d_positions,
+                          hipStream_t s);
+
 // synthetic generators
 hipError_t launch_synth_genome(uint64_t seed, uint64_t length, uint8_t* out, hipStream_t s);
 hipError_t launch_synth_kmers(uint64_t seed, uint64_t first, uint64_t N, int k, uint8_t* out, hipStream_t s);

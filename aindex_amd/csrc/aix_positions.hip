@@ -1,0 +1,156 @@
+// aix_positions.hip — A1/A2 rows: the positions index ("aindex") of a reads buffer.
+//   A1 AIndexCompressed ctor   src/hash.hpp:365-399      indices = exclusive prefix sum of tf
+//   A2 lu_compressed_worker    src/hash.cpp:960-1060     positions[indices[h] + slot] = offset + 1, slot < tf[h]
+//
+// The reference assigns slots with fetch_add in thread-arrival order (ascending offsets with one thread; SURVEY
+// §8a-A2). Here every window's bucket is computed in parallel, then a STABLE radix sort by bucket (rocPRIM) of the
+// window offsets (a counting iterator, i.e. already ascending) yields each bucket's offsets in ascending order —
+// exactly the 1-thread reference result, deterministically — and the first tf[h] of them are placed.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "aix_internal.hpp"
+
+namespace aix {
+
+static constexpr int kB = 256;
+static inline unsigned grid_of(uint64_t work) {
+    uint64_t b = (work + kB - 1) / kB;
+    if (b > 8192) b = 8192;
+    if (b == 0) b = 1;
+    return (unsigned)b;
+}
+
+__device__ __forceinline__ void ld23(const uint8_t* p, uint64_t& w0, uint64_t& w1, uint64_t& w2) {
+    const uintptr_t a = (uintptr_t)p;
+    const uint32_t o = (uint32_t)(a & 3);
+    const uint32_t* q = (const uint32_t*)(a - o);
+    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4], d5 = q[5];
+    const uint32_t d6 = (o >= 2) ? q[6] : 0u;
+    const uint32_t sh = o * 8;
+    const uint32_t e0 = __funnelshift_r(d0, d1, sh), e1 = __funnelshift_r(d1, d2, sh);
+    const uint32_t e2 = __funnelshift_r(d2, d3, sh), e3 = __funnelshift_r(d3, d4, sh);
+    const uint32_t e4 = __funnelshift_r(d4, d5, sh), e5 = __funnelshift_r(d5, d6, sh) & 0x00FFFFFFu;
+    w0 = e0 | ((uint64_t)e1 << 32);
+    w1 = e2 | ((uint64_t)e3 << 32);
+    w2 = e4 | ((uint64_t)e5 << 32);
+}
+// any byte of x (restricted to `mask` bytes) equal to c ?
+__device__ __forceinline__ bool has_byte(uint64_t x, uint8_t c, uint64_t mask) {
+    const uint64_t z = (x ^ (0x0101010101010101ULL * c)) | ~mask;
+    return (((z - 0x0101010101010101ULL) & ~z) & 0x8080808080808080ULL) != 0;
+}
+
+__global__ void __launch_bounds__(kB) k_tf_u64(const KeyRec* __restrict__ recs, uint64_t n, uint64_t* __restrict__ tf64) {
+    const uint64_t stride = (uint64_t)gridDim.x * kB;
+    for (uint64_t i = (uint64_t)blockIdx.x * kB + threadIdx.x; i <= n; i += stride) tf64[i] = i < n ? (uint64_t)recs[i].tf : 0ull;
+}
+
+// bucket of every window (key = n for "no bucket"): hash.cpp:1004-1052
+__global__ void __launch_bounds__(kB) k_a2_probe(const IndexDev ix, const uint8_t* __restrict__ buf, uint64_t nwin, uint64_t start, uint32_t* __restrict__ keys) {
+    const uint64_t stride = (uint64_t)gridDim.x * kB;
+    const uint64_t FULL = ~0ULL, LAST7 = 0x00FFFFFFFFFFFFFFULL;
+    for (uint64_t i = (uint64_t)blockIdx.x * kB + threadIdx.x; i < nwin; i += stride) {
+        uint32_t key = (uint32_t)ix.n;
+        if (i >= start) {
+            uint64_t w0, w1, w2;
+            ld23(buf + i, w0, w1, w2);
+            const bool skip = has_byte(w0, '\n', FULL) || has_byte(w1, '\n', FULL) || has_byte(w2, '\n', LAST7) ||
+                              has_byte(w0, '~', FULL) || has_byte(w1, '~', FULL) || has_byte(w2, '~', LAST7) ||
+                              has_byte(w0, 'N', FULL) || has_byte(w1, 'N', FULL) || has_byte(w2, 'N', LAST7);      // :1006-1011
+            if (!skip) {
+                const Enc23 e = encode23_words(w0, w1, w2);                    // get_dna23_bitset: non-ACGT -> 0
+                const uint64_t r = revcomp(e.code, 23);
+                uint64_t a, b, c, want;
+                if (e.code <= r) {                                            // :1032: probe the numerically smaller strand only
+                    jenkins23(w0, w1, w2, ix.m.seed, a, b, c);                 // raw bytes of the window
+                    want = e.code;
+                } else {
+                    uint64_t r0, r1, r2;
+                    ascii23_of_rc(e.code, r0, r1, r2);
+                    jenkins23(r0, r1, r2, ix.m.seed, a, b, c);
+                    want = r;
+                }
+                const uint64_t h = mphf_from_hash(ix.m, a, b, c);
+                if (h < ix.n && ix.keys[h].code == want) key = (uint32_t)h;
+            }
+        }
+        keys[i] = key;
+    }
+}
+
+__global__ void __launch_bounds__(kB) k_a2_first(const uint32_t* __restrict__ skeys, uint64_t nwin, uint32_t n, uint32_t* __restrict__ first) {
+    const uint64_t stride = (uint64_t)gridDim.x * kB;
+    for (uint64_t j = (uint64_t)blockIdx.x * kB + threadIdx.x; j < nwin; j += stride) {
+        const uint32_t h = skeys[j];
+        if (h < n && (j == 0 || skeys[j - 1] != h)) first[h] = (uint32_t)j;
+    }
+}
+__global__ void __launch_bounds__(kB) k_a2_place(const IndexDev ix, const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ svals, uint64_t nwin,
+                                                const uint32_t* __restrict__ first, const uint64_t* __restrict__ indices, uint64_t* __restrict__ positions) {
+    const uint64_t stride = (uint64_t)gridDim.x * kB;
+    const uint32_t n = (uint32_t)ix.n;
+    for (uint64_t j = (uint64_t)blockIdx.x * kB + threadIdx.x; j < nwin; j += stride) {
+        const uint32_t h = skeys[j];
+        if (h >= n) continue;
+        const uint64_t rank = j - first[h];
+        if (rank < ix.keys[h].tf) positions[indices[h] + rank] = (uint64_t)svals[j] + 1;     // :1037-1040, 1-based offsets
+    }
+}
+
+// indices (device, n+1 entries). Returns hip error.
+hipError_t positions_indices(const IndexDev& ix, uint64_t* d_indices, hipStream_t s) {
+    const uint64_t n = ix.n;
+    uint64_t* tf64 = nullptr;
+    hipError_t e = hipMalloc((void**)&tf64, 8 * (n + 1));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_tf_u64, dim3(grid_of(n + 1)), dim3(kB), 0, s, ix.keys, n, tf64);
+    size_t tmp_bytes = 0;
+    e = rocprim::exclusive_scan(nullptr, tmp_bytes, tf64, d_indices, (uint64_t)0, (size_t)(n + 1), rocprim::plus<uint64_t>(), s);
+    void* tmp = nullptr;
+    if (e == hipSuccess) e = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1);
+    if (e == hipSuccess) e = rocprim::exclusive_scan(tmp, tmp_bytes, tf64, d_indices, (uint64_t)0, (size_t)(n + 1), rocprim::plus<uint64_t>(), s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (tmp) (void)hipFree(tmp);
+    (void)hipFree(tf64);
+    return e;
+}
+
+// positions (device, pre-zeroed, indices[n] entries) for a reads buffer in HBM. len < 2^32.
+hipError_t positions_fill(const IndexDev& ix, const uint8_t* d_reads, uint64_t len, uint64_t start, const uint64_t* d_indices, uint64_t* d_positions,
+                          hipStream_t s) {
+    if (len < 23 || ix.n == 0) return hipSuccess;
+    const uint64_t nwin = len - 22;
+    uint32_t *keys = nullptr, *skeys = nullptr, *svals = nullptr, *first = nullptr;
+    void* tmp = nullptr;
+    hipError_t e = hipMalloc((void**)&keys, 4 * nwin);
+    if (e == hipSuccess) e = hipMalloc((void**)&skeys, 4 * nwin);
+    if (e == hipSuccess) e = hipMalloc((void**)&svals, 4 * nwin);
+    if (e == hipSuccess) e = hipMalloc((void**)&first, 4 * ix.n);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_a2_probe, dim3(grid_of(nwin)), dim3(kB), 0, s, ix, d_reads, nwin, start, keys);
+        e = hipGetLastError();
+    }
+    unsigned end_bit = 1;
+    while (end_bit < 32 && (ix.n >> end_bit)) ++end_bit;                        // keys are in [0, n]
+    size_t tmp_bytes = 0;
+    rocprim::counting_iterator<uint32_t> iota(0);
+    if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, skeys, iota, svals, (size_t)nwin, 0u, end_bit, s);
+    if (e == hipSuccess) e = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1);
+    if (e == hipSuccess) e = rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, skeys, iota, svals, (size_t)nwin, 0u, end_bit, s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_a2_first, dim3(grid_of(nwin)), dim3(kB), 0, s, skeys, nwin, (uint32_t)ix.n, first);
+        hipLaunchKernelGGL(k_a2_place, dim3(grid_of(nwin)), dim3(kB), 0, s, ix, skeys, svals, nwin, first, d_indices, d_positions);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (tmp) (void)hipFree(tmp);
+    if (keys) (void)hipFree(keys);
+    if (skeys) (void)hipFree(skeys);
+    if (svals) (void)hipFree(svals);
+    if (first) (void)hipFree(first);
+    return e;
+}
+
+}  // namespace aix

@@ -234,6 +234,17 @@ class Index:
         check(lib().aix_count23_fixed(self._h, _np_ptr(a), a.shape[0], fmt, canon_mode, _np_ptr(out)), "aix_count23_fixed")
         return out
 
+    def positions_fill(self, reads: bytes):
+        """A1 + A2: (indices uint64[n+1], positions uint64[sum tf]) = the .indices.bin / .index.bin images."""
+        a = np.frombuffer(reads, dtype=np.uint8)
+        indices = np.empty(self.n + 1, dtype=np.uint64)
+        total = C.c_uint64()
+        check(lib().aix_positions_fill(self._h, _np_ptr(a), a.shape[0], _np_ptr(indices), None, 0, C.byref(total)), "aix_positions_fill")
+        pos = np.zeros(total.value, dtype=np.uint64)
+        check(lib().aix_positions_fill(self._h, _np_ptr(a), a.shape[0], _np_ptr(indices), _np_ptr(pos), pos.shape[0], C.byref(total)),
+              "aix_positions_fill")
+        return indices, pos
+
     # ---- HBM-resident (torch) entry points: asynchronous on torch's current stream ------------
     def _chk_dev(self, t):
         if not t.is_cuda or t.device.index != self.device:

@@ -40,6 +40,11 @@ class AindexWrapper:
         self.n_reads = 0
         self.n_kmers = 0
         self.reads_size = 0
+        self.max_tf = 0
+        self._reads = None
+        self._positions = None
+        self._indices = None
+        self._ridx_start = None
 
     # ---- loaders -----------------------------------------------------------------------------
     @staticmethod
@@ -81,16 +86,83 @@ class AindexWrapper:
         if reads_file:
             self.load_reads(reads_file)
 
-    # positions / reads access belong to the "next" tier
+    # ---- reads + positions index (N2/N4 tier: host-side views over the reference's files) ---------
+    def load_reads_index(self, index_file: str):
+        """:261-279 — `.ridx` lines "rid\tstart\tend"; intervals are (start, end + 1)."""
+        self._need(index_file)
+        a = np.loadtxt(index_file, dtype=np.uint64, ndmin=2) if os.path.getsize(index_file) else np.zeros((0, 3), np.uint64)
+        self._ridx_rid, self._ridx_start, self._ridx_end = a[:, 0].copy(), a[:, 1].copy(), a[:, 2].copy()
+        self.n_reads = int(a.shape[0])
+
     def load_reads(self, reads_file: str):
-        raise NotImplementedError("reads access (python_wrapper.cpp:281-359) is outside the hot path built so far")
+        """:281-322 — mmap the reads file and read the sibling `.ridx`."""
+        self._need(reads_file)
+        self._reads = np.memmap(reads_file, dtype=np.uint8, mode="r")
+        self.reads_size = int(self._reads.shape[0])
+        self.load_reads_index(reads_file[: reads_file.rfind(".")] + ".ridx")
 
-    def load_aindex(self, *a, **k):
-        raise NotImplementedError("position index loading (python_wrapper.cpp:361-402) is outside the hot path built so far")
+    load_reads_in_memory = load_reads                                                   # :324-359
 
-    load_aindex_from_prefix_23mer = load_aindex
-    load_13mer_aindex = load_aindex
-    load_aindex_from_prefix_13mer = load_aindex
+    def load_aindex(self, index_file: str, indices_file: str, max_tf: int = 0):
+        """:361-402 — .index.bin (positions, 1-based, 0 = empty) and .indices.bin (n+1 offsets)."""
+        self._need(index_file, indices_file)
+        self._need23()
+        self._positions = np.memmap(index_file, dtype=np.uint64, mode="r") if os.path.getsize(index_file) else np.zeros(0, np.uint64)
+        self._indices = np.memmap(indices_file, dtype=np.uint64, mode="r")
+        self.max_tf = max_tf
+        self.aindex_loaded = True
+
+    def load_aindex_from_prefix_23mer(self, prefix: str, max_tf: int = 0, reads_file: str = ""):
+        self.load_aindex(prefix + ".index.bin", prefix + ".indices.bin", max_tf)       # :1134-1160
+        if reads_file and getattr(self, "_reads", None) is None:
+            self.load_reads(reads_file)
+
+    def load_13mer_aindex(self, index_file: str, indices_file: str):
+        """:439-471 maps only the indices; 13-mer positions are never set, so queries return []."""
+        self._need(indices_file)
+        self.aindex_loaded = True
+
+    def load_aindex_from_prefix_13mer(self, prefix: str, reads_file: str = ""):
+        self.load_13mer_aindex(prefix + ".index.bin", prefix + ".indices.bin")
+
+    def build_aindex(self, reads_file: str, prefix: Optional[str] = None):
+        """compute_aindex replacement (A1/A2 on the GPU): returns (indices, positions) and, with a prefix,
+        writes `<prefix>.indices.bin` / `<prefix>.index.bin` exactly like the reference (hash.hpp:470-486)."""
+        reads = open(reads_file, "rb").read()
+        indices, pos = self._need23().positions_fill(reads)
+        if prefix:
+            pos.tofile(prefix + ".index.bin")
+            indices.tofile(prefix + ".indices.bin")
+        return indices, pos
+
+    def get_read_by_rid(self, rid: int) -> str:
+        if getattr(self, "_reads", None) is None or rid >= self.n_reads or rid < 0:     # :666-675
+            return ""
+        return bytes(self._reads[int(self._ridx_start[rid]):int(self._ridx_end[rid])]).decode("latin-1")
+
+    def get_read(self, start: int, end: int, revcomp: bool = False) -> str:
+        if getattr(self, "_reads", None) is None or start >= self.reads_size or end >= self.reads_size or start > end:
+            return ""                                                                    # :677-698
+        b = bytes(self._reads[start:end])
+        if revcomp:
+            b = b[::-1].translate(_COMP)
+        return b.decode("latin-1")
+
+    def _interval(self, pos: int):
+        if not self.aindex_loaded or getattr(self, "_ridx_start", None) is None or self.n_reads == 0:
+            return None
+        # IntervalTree::query(pos, pos + 1) of python_wrapper.cpp:66-74: first interval in file order with
+        # start <= pos + 1 and (end + 1) >= pos
+        hit = np.nonzero((self._ridx_start <= np.uint64(pos + 1)) & (self._ridx_end + np.uint64(1) >= np.uint64(pos)))[0]
+        return int(hit[0]) if hit.shape[0] else None
+
+    def get_rid(self, pos: int) -> int:
+        i = self._interval(pos)                                                          # :757-772
+        return int(self._ridx_rid[i]) if i is not None else 0
+
+    def get_start(self, pos: int) -> int:
+        i = self._interval(pos)                                                          # :774-789
+        return int(self._ridx_start[i]) if i is not None else 0
 
     # ---- helpers -----------------------------------------------------------------------------
     def _need23(self) -> Index:
@@ -290,12 +362,36 @@ class AindexWrapper:
         return (f"23-mer Index Statistics:\nTotal k-mers: {self.n_kmers}\nTotal reads: {self.n_reads}\n"
                 f"AIndex loaded: {'Yes' if self.aindex_loaded else 'No'}\nReads loaded: No\nHash map size: {self.get_hash_size()}\n")
 
-    # positions: get_positions dispatches on len 13/23 (:826-831); without a loaded position index the
-    # reference returns [] for 13-mers and aborts for absent 23-mers — [] here.
+    # ---- positions (get_positions dispatches on length, :826-831) ---------------------------------
     def get_positions(self, kmer: str) -> List[int]:
+        b = _enc(kmer)
+        if len(b) == 13:
+            return self.get_positions_13mer(kmer)
+        if len(b) == 23:
+            return self.get_positions_23mer(kmer)
         return []
 
-    get_positions_13mer = get_positions
+    def get_positions_13mer(self, kmer: str) -> List[int]:
+        return []                                    # positions_13mer is never mapped in the reference (:439-471)
+
+    def get_positions_23mer(self, kmer: str) -> List[int]:
+        """:800-822 via PHASH_MAP::get_pfid (hash.hpp:150-170): the lexicographically smaller of the k-mer and the
+        decode of its reverse complement is looked up; an absent k-mer gives [] (the reference reads
+        indices[n+1] out of bounds there)."""
+        if self._ix23 is None or getattr(self, "_positions", None) is None:
+            return []
+        b = _enc(kmer)
+        code = 0
+        for c in b:
+            code = (code << 2) | {65: 0, 67: 1, 71: 2, 84: 3}.get(c, 0)
+        rc = _lib.lib().aix_selftest_revcomp(code, 23)
+        rev = self._decode23(rc).encode()
+        s, want = (b, code) if b <= rev else (rev, rc)
+        h = int(self._ix23.hash_ascii(s)[0])
+        if h >= self._ix23.n or int(self._checker()[h]) != want:
+            return []
+        seg = np.asarray(self._positions[int(self._indices[h]):int(self._indices[h + 1])])
+        return (seg[seg != 0] - np.uint64(1)).tolist()
 
     def close(self):
         for ix in (self._ix23, self._ix13):

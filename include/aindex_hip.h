@@ -178,6 +178,15 @@ int aix_count23_fixed_dev(aix_index_t* h, const char* d_plain, uint64_t len, int
  * window contains any other byte. d_codes holds len-k+1 entries. Distinct k-mers and their counts are
  * the sort + run-length of the valid entries (aindex_amd/counting.py). 1 <= k <= 32. */
 int aix_window_codes_dev(const char* d_plain, uint64_t len, int k, int canon_mode, uint64_t* d_codes, void* stream);
+/* A1 + A2: replaces `compute_aindex <reads> <pf> <prefix> <threads> 23 <tf> <kmers.bin> <kmers.txt>`
+ * (src/compute_aindex.cpp:28-116): indices_out[n+1] = exclusive prefix sum of tf (AIndexCompressed ctor,
+ * src/hash.hpp:365-399) = the .indices.bin image; positions_out[indices[n]] = the .index.bin image:
+ * for every 23-byte window of the `.reads` buffer without '\n', '~', 'N', probing only the numerically smaller
+ * strand, positions[indices[h] + slot] = offset + 1 for the first tf[h] occurrences in ascending offset order —
+ * the result of the reference run with ONE thread (lu_compressed_worker, src/hash.cpp:960-1060; its multi-thread
+ * slot order is schedule dependent). positions_out may be NULL to query *total_out = indices[n] first. len < 2^32. */
+int aix_positions_fill(aix_index_t* h, const char* reads, uint64_t len, uint64_t* indices_out, uint64_t* positions_out,
+                       uint64_t positions_cap, uint64_t* total_out);
 /* Host-side record normalisation to PLAIN form (readers of count_kmers13.cpp:211-272 /
  * count_kmers.cpp:250-295): out must hold len+1 bytes; *out_len receives the normalised length.
  * fasta_mode: 0 = count_kmers13 rules, 1 = kmer_counter rules ('>' anywhere starts a record). */

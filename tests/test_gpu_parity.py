@@ -356,3 +356,111 @@ def test_properties_at_scale(canon_case):
     assert np.array_equal(tf_fwd, counts) and np.array_equal(tf_rc, counts)
     tot = ix.total_ascii(synth.decode_kmers(keys[:100_000], 23))
     assert np.array_equal(tot, 2 * counts[:100_000].astype(np.uint64))
+
+
+# ------------------------------------------------------------------------------------------------
+# A1/A2 positions index and the Python mirrors
+# ------------------------------------------------------------------------------------------------
+def test_positions_fill_equals_compute_aindex(ix23, gold, small23_prefix):
+    z = np.load(os.path.join(gold, "small23", "aindex.npz"))
+    reads = open(small23_prefix + ".reads", "rb").read()
+    indices, pos = ix23.positions_fill(reads)
+    assert np.array_equal(indices, z["indices"])
+    assert np.array_equal(pos, z["index"])            # the reference's 1-thread run, slot for slot
+
+
+def test_positions_fill_vs_oracle_true_canonical(canon_case):
+    ix, orc = canon_case["ix"], canon_case["orc"]
+    asc = synth.genome_ascii(23, 300_000)
+    r = synth.reads_plain(41, asc, 4000, 150, rc_fraction_half=True, n_rate_ppm=2000).reshape(-1, 151).copy()
+    r[::7, 150] = ord("~")                            # PE separator inside a line
+    r[5::50, 10] = ord("?")
+    r[3::40] |= 0x20                                   # lower-case reads: raw bytes hashed on the forward strand
+    r[3::40, 150] = ord("\n")
+    reads = b"?AC\n" + r.tobytes()                    # exercises the start-adjust quirk (hash.cpp:973-986)
+    want_ind, want_pos = orc.positions(reads)
+    indices, pos = ix.positions_fill(reads)
+    assert np.array_equal(indices, want_ind)
+    assert np.array_equal(pos, want_pos)
+    assert (pos != 0).sum() > 100_000
+
+
+def test_python_mirrors(gold, small23_prefix, tmp_path):
+    from aindex_amd.aindex import AIndex, Strand
+    q = load(gold, "small23", "queries.json")
+    ai = AIndex.load_from_prefix(small23_prefix)                  # auto-detect picks 23 (.kmers.bin present)
+    qs = q["queries"]
+    assert ai.get_tf_values(qs) == q["tf"]
+    assert [ai.get_tf_value(s) for s in qs[:20]] == q["tf"][:20]
+    assert [ai[s] for s in qs[300:320]] == q["tf"][300:320]
+    assert ai.get_hash_values(qs[:100]) == q["hash"][:100]
+    assert [int(ai.get_strand(s)) for s in qs[290:310]] == q["strand"][290:310]
+    assert [ai.get_kid_by_kmer(s) for s in qs[:30]] == q["kid"][:30]
+    assert len(ai) == q["hash_size"] and ai.n_kmers == q["n_kmers"]
+    w = ai._wrapper
+    assert w.get_total_tf_values_23mer(qs) == q["total"]
+    assert [list(p) for p in w.get_tf_both_directions_23mer_batch(qs)] == q["both"]
+    for c in q["coverage"]:
+        assert ai.get_sequence_coverage(c["seq"], c["cutoff"], 23) == c["cov"]
+    kid = q["kid"][0]
+    kmer = ai.get_kmer_by_kid(kid)
+    assert kmer == qs[0] and ai.get_kmer_info(kid)[2] == q["tf"][0]
+    assert Strand(1) == ai.get_strand(qs[0])
+    # positions: build with the GPU, write the reference's files, query through the mirror
+    prefix = str(tmp_path / "s23")
+    indices, pos = w.build_aindex(small23_prefix + ".reads", prefix)
+    z = np.load(os.path.join(gold, "small23", "aindex.npz"))
+    assert np.array_equal(np.fromfile(prefix + ".index.bin", dtype=np.uint64), z["index"])
+    assert np.array_equal(np.fromfile(prefix + ".indices.bin", dtype=np.uint64), z["indices"])
+    w.load_aindex_from_prefix_23mer(prefix, 100)
+    reads = open(small23_prefix + ".reads", "rb").read()
+    found = 0
+    for s in qs[:50] + qs[300:350]:
+        got = w.get_positions(s)
+        for p in got:
+            win = reads[p:p + 23].decode()
+            assert win == s or win == w.get_reverse_complement_23mer(s)
+        found += len(got)
+    assert found > 50
+    assert w.get_positions("ACGT") == [] and w.get_positions(qs[700]) == []
+
+
+def test_tools_cli(gold, small23_prefix, tmp_path):
+    from aindex_amd import tools
+    out = str(tmp_path / "o")
+    os.makedirs(out)
+    cwd = os.getcwd()
+    os.chdir(out)
+    try:
+        assert tools.main(["kmer_counter", os.path.join(gold, "small23", "reads.fa"), "23", "kc.txt", "-t", "4"]) == 0
+        rows = sorted(ln for ln in open("output.txt").read().split("\n") if ln)
+        want = sorted(ln for ln in open(small23_prefix + ".dat").read().split("\n") if ln)
+        assert rows == want
+        open("keys.txt", "w").write("".join(r.split("\t")[0] + "\n" for r in open(small23_prefix + ".dat").read().split("\n") if r))
+        assert tools.main(["compute_mphf_seq", "keys.txt", "t.pf"]) == 0
+        assert open("t.pf", "rb").read() == open(small23_prefix + ".pf", "rb").read()
+        assert tools.main(["compute_index", small23_prefix + ".dat", "t.pf", "t", "4", "0"]) == 0
+        assert open("t.kmers.bin", "rb").read() == open(small23_prefix + ".kmers.bin", "rb").read()
+        assert open("t.tf.bin", "rb").read() == open(small23_prefix + ".tf.bin", "rb").read()
+    finally:
+        os.chdir(cwd)
+
+
+def test_kmer_counter_sets_golden(gold):
+    from aindex_amd import counting
+    fa = open(os.path.join(gold, "kmer_counter", "mixed.fa"), "rb").read()
+    for k in (23, 13):
+        for mc in (1, 2):
+            rows = [ln.split("\t") for ln in open(os.path.join(gold, "kmer_counter", f"mixed.k{k}.m{mc}.tsv")).read().split("\n") if ln]
+            want = sorted((r[0], int(r[1])) for r in rows)
+            keys, counts = counting.count_distinct(fa, k, _lib.CANON_REF_X86, mc)
+            got = sorted((bytes(a).decode(), int(c)) for a, c in zip(synth.decode_kmers(keys, k), counts))
+            assert got == want
+    # TRUE_RC mode against the oracle (semantics of tests/analyze_kmers.py)
+    keys, counts = counting.count_distinct(fa, 23, _lib.CANON_TRUE_RC, 1)
+    okeys, ocnt = O.count_distinct(fa, 23, 2, 1)
+    assert np.array_equal(keys, okeys) and np.array_equal(counts, ocnt)
+    # generic-k path (k not 13/23)
+    keys, counts = counting.count_distinct(fa, 17, _lib.CANON_NONE, 1)
+    okeys, ocnt = O.count_distinct(fa, 17, 0, 1)
+    assert np.array_equal(keys, okeys) and np.array_equal(counts, ocnt)
