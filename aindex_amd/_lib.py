@@ -51,6 +51,7 @@ SIGNATURES = {
     "aix_index_close": (i32, [vp]),
     "aix_index_info": (i32, [vp, C.POINTER(Info)]),
     "aix_index_set_canonical_fastpath": (i32, [vp, i32]),
+    "aix_index_set_fingerprint_filter": (i32, [vp, i32]),
     "aix_index_set_tf_13": (i32, [vp, vp]),
     "aix_index_get_tf": (i32, [vp, vp, u64]),
     "aix_index_get_checker": (i32, [vp, vp, u64]),

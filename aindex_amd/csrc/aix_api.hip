@@ -65,6 +65,8 @@ struct aix_index {
     uint64_t device_bytes = 0;
     bool canonical_only = false;
     bool canonical_fastpath = true;
+    bool has_fp = false;
+    bool fp_filter = true;
     std::mutex count_mutex;
 
     IndexDev dev() const {
@@ -80,6 +82,7 @@ struct aix_index {
         d.tf13_mphf = tf13_mphf;
         d.canonical_only = (canonical_only && canonical_fastpath) ? 1u : 0u;
         d.k = k;
+        d.use_fp = (has_fp && fp_filter) ? 1u : 0u;
         return d;
     }
 };
@@ -162,6 +165,7 @@ static int upload_mphf(aix_index* h, const uint8_t* pf, uint64_t len) {
         recs[i].word = w;
         recs[i].prefix = (uint32_t)run;
         recs[i].pad = 0;
+        recs[i].fp[0] = recs[i].fp[1] = recs[i].fp[2] = recs[i].fp[3] = 0;
         run += popc_pairs(w);
     }
     if (run >> 32) return AIX_ERR_UNSUPPORTED;
@@ -208,6 +212,9 @@ static int adopt_device_arrays(aix_index* h, const uint64_t* d_checker, const ui
     (void)hipFree(d_flag);
     HIPCHK(e);
     h->canonical_only = (flag == 0);
+    HIPCHK(launch_set_fingerprints(h->dev().m, h->recs, h->keys, n, s));
+    HIPCHK(hipStreamSynchronize(s));
+    h->has_fp = true;
     return AIX_OK;
 }
 
@@ -388,6 +395,12 @@ extern "C" int aix_index_info(const aix_index_t* h, aix_info_t* info) {
 extern "C" int aix_index_set_canonical_fastpath(aix_index_t* h, int enabled) {
     if (!h) return AIX_ERR_ARG;
     h->canonical_fastpath = enabled != 0;
+    return AIX_OK;
+}
+
+extern "C" int aix_index_set_fingerprint_filter(aix_index_t* h, int enabled) {
+    if (!h) return AIX_ERR_ARG;
+    h->fp_filter = enabled != 0;
     return AIX_OK;
 }
 

@@ -22,10 +22,19 @@ namespace aix {
 // One record per 64-bit word of the emphf bit-pair vector: the word itself plus the number of
 // non-zero pairs in all words before it. rank(pos) = prefix + popc_pairs(word & mask(pos)), so a
 // lookup needs exactly three independent 16-byte reads and no dependent rank-directory read.
-struct __attribute__((aligned(16))) BvRec {
+// The second half holds a 4-bit fingerprint per bit-pair position: the fingerprint of the key whose assigned
+// (hidx-selected) node is that position. A probe whose fingerprint differs from the stored one cannot match
+// checker[rank] and is answered "absent" without touching the key table (15/16 of all misses).
+struct __attribute__((aligned(16))) BvHead {
     uint64_t word;
     uint32_t prefix;
     uint32_t pad;
+};
+struct __attribute__((aligned(32))) BvRec {
+    uint64_t word;
+    uint32_t prefix;
+    uint32_t pad;
+    uint32_t fp[4];      // 32 x 4 bits, nibble j = fingerprint of the key assigned to pair j (0 if none)
 };
 // checker[] and tf[] of PHASH_MAP (hash.hpp:82-121) interleaved: one 16-byte read per probe.
 struct __attribute__((aligned(16))) KeyRec {
@@ -262,13 +271,43 @@ struct MphfDev {
     FastMod fm;
 };
 
+__device__ __forceinline__ BvHead load_head(const BvRec* recs, uint64_t i) { return *(const BvHead*)(recs + i); }
+
+// 4-bit fingerprint of a key, taken from hash bits that the node computation does not expose
+__device__ __forceinline__ uint32_t fp_of_hash(uint64_t a, uint64_t b, uint64_t c) { return (uint32_t)((a ^ b ^ c) >> 60); }
+
+// mphf::lookup plus the stored fingerprint of the selected node and the node itself
+__device__ __forceinline__ uint64_t mphf_from_hash_fp(const MphfDev& m, uint64_t a, uint64_t b, uint64_t c, uint32_t& fp_stored, uint64_t& node) {
+    const uint64_t n0 = fastmod(a, m.fm);
+    const uint64_t n1 = m.D + fastmod(b, m.fm);
+    const uint64_t n2 = 2 * m.D + fastmod(c, m.fm);
+    const BvHead r0 = load_head(m.recs, n0 >> 5);
+    const BvHead r1 = load_head(m.recs, n1 >> 5);
+    const BvHead r2 = load_head(m.recs, n2 >> 5);
+    // the three candidate fingerprint dwords are read up front, next to their heads (same 32-byte record, no new
+    // line). Measured: 17.5 G lookups/s this way vs 16.4 G/s with one dependent read after hidx is known.
+    const uint32_t f0 = m.recs[n0 >> 5].fp[(n0 & 31) >> 3];
+    const uint32_t f1 = m.recs[n1 >> 5].fp[(n1 & 31) >> 3];
+    const uint32_t f2 = m.recs[n2 >> 5].fp[(n2 & 31) >> 3];
+    const uint32_t s0 = (uint32_t)(n0 & 31) * 2, s1 = (uint32_t)(n1 & 31) * 2, s2 = (uint32_t)(n2 & 31) * 2;
+    const uint32_t v = (uint32_t)((r0.word >> s0) & 3) + (uint32_t)((r1.word >> s1) & 3) + (uint32_t)((r2.word >> s2) & 3);
+    const uint32_t hidx = v - 3u * ((v * 11u) >> 5);
+    const uint64_t w = hidx == 0 ? r0.word : (hidx == 1 ? r1.word : r2.word);
+    const uint32_t p = hidx == 0 ? r0.prefix : (hidx == 1 ? r1.prefix : r2.prefix);
+    const uint32_t sh = hidx == 0 ? s0 : (hidx == 1 ? s1 : s2);
+    node = hidx == 0 ? n0 : (hidx == 1 ? n1 : n2);
+    const uint32_t f = hidx == 0 ? f0 : (hidx == 1 ? f1 : f2);
+    fp_stored = (f >> ((sh & 15) * 2)) & 15u;                      // nibble (node & 7) of the dword: sh = 2*(node & 31)
+    return (uint64_t)p + popc_pairs(w & ((1ULL << sh) - 1));
+}
+
 __device__ __forceinline__ uint64_t mphf_from_hash(const MphfDev& m, uint64_t a, uint64_t b, uint64_t c) {
     const uint64_t n0 = fastmod(a, m.fm);
     const uint64_t n1 = m.D + fastmod(b, m.fm);
     const uint64_t n2 = 2 * m.D + fastmod(c, m.fm);
-    const BvRec r0 = m.recs[n0 >> 5];
-    const BvRec r1 = m.recs[n1 >> 5];
-    const BvRec r2 = m.recs[n2 >> 5];
+    const BvHead r0 = load_head(m.recs, n0 >> 5);
+    const BvHead r1 = load_head(m.recs, n1 >> 5);
+    const BvHead r2 = load_head(m.recs, n2 >> 5);
     const uint32_t s0 = (uint32_t)(n0 & 31) * 2, s1 = (uint32_t)(n1 & 31) * 2, s2 = (uint32_t)(n2 & 31) * 2;
     const uint32_t v = (uint32_t)((r0.word >> s0) & 3) + (uint32_t)((r1.word >> s1) & 3) + (uint32_t)((r2.word >> s2) & 3);
     const uint32_t hidx = v - 3u * ((v * 11u) >> 5);               // v in 0..9 -> v % 3

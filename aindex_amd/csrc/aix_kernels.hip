@@ -60,9 +60,16 @@ __device__ __forceinline__ Probe probe23(const IndexDev& ix, uint64_t w0, uint64
     uint64_t a, b, c;
     jenkins23(w0, w1, w2, ix.m.seed, a, b, c);
     Probe r;
-    r.slot = mphf_from_hash(ix.m, a, b, c);
     r.found = false;
     r.tf = 0;
+    if (ix.use_fp) {
+        uint32_t fps;
+        uint64_t node;
+        r.slot = mphf_from_hash_fp(ix.m, a, b, c, fps, node);
+        if (fps != fp_of_hash(a, b, c)) return r;  // the key assigned to this node (if any) is a different key
+    } else {
+        r.slot = mphf_from_hash(ix.m, a, b, c);
+    }
     if (r.slot < ix.n) {                           // python_wrapper.cpp:613 `h1 >= n ||`
         const KeyRec k = ix.keys[r.slot];
         if (k.code == code) { r.found = true; r.tf = k.tf; }
@@ -352,6 +359,23 @@ __global__ void __launch_bounds__(kBlock) k_extract(const KeyRec* __restrict__ r
         if (checker) checker[i] = r.code;
     }
 }
+// Fingerprints: for every stored code that sits in its own MPHF slot, write its 4-bit fingerprint into the nibble
+// of its assigned node. Entries that are not where the MPHF puts them (corrupt / foreign index) are skipped, so a
+// fingerprint mismatch always implies checker[rank] != query.
+__global__ void __launch_bounds__(kBlock) k_set_fp(const MphfDev m, BvRec* __restrict__ recs, const KeyRec* __restrict__ keys, uint64_t n) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint64_t code = keys[i].code;
+        if (code >> 46) continue;
+        uint64_t w0, w1, w2, a, b, c, node;
+        uint32_t fps;
+        ascii23_of_rc(revcomp(code, 23), w0, w1, w2);
+        jenkins23(w0, w1, w2, m.seed, a, b, c);
+        if (mphf_from_hash_fp(m, a, b, c, fps, node) != i) continue;
+        atomicOr(&recs[node >> 5].fp[(node & 31) >> 3], fp_of_hash(a, b, c) << (4 * (uint32_t)(node & 7)));
+    }
+}
+
 // I1 (hash.cpp:671-723): checker[h] = code, tf[h] = count with h = mphf(key). Keys arrive either as
 // n x 23 ASCII bytes (the .dat lines) or as 2-bit codes. A slot hit twice raises `conflict`
 // (the reference detects it only when the earlier tf was non-zero, then exit(12)).
@@ -433,6 +457,8 @@ __global__ void __launch_bounds__(kBlock) k_count23_fixed(const IndexDev ix, con
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     if (len < 23) return;
     const uint64_t nwin = len - 22;
+    IndexDev ixn = ix;
+    ixn.use_fp = 0;               // windows of reads drawn from the indexed genome are hits: the filter only costs
     for (uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x; p < nwin; p += stride) {
         uint64_t w0, w1, w2;
         load23(buf + p, w0, w1, w2);
@@ -446,7 +472,7 @@ __global__ void __launch_bounds__(kBlock) k_count23_fixed(const IndexDev ix, con
         else if (canon_mode == 2) { const uint64_t x = revcomp(e.code, 23); key = e.code < x ? e.code : x; }
         uint64_t s0, s1, s2;
         ascii23_of_rc(revcomp(key, 23), s0, s1, s2);
-        const Probe pr = probe23(ix, s0, s1, s2, key);
+        const Probe pr = probe23(ixn, s0, s1, s2, key);
         if (pr.found) atomicAdd(&tf_out[pr.slot], 1u);
     }
 }
@@ -557,7 +583,7 @@ __global__ void __launch_bounds__(kBlock) k_gather(const uint8_t* __restrict__ t
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             if (ELEM == 16) {
-                const BvRec r = ((const BvRec*)table)[idx[u]];
+                const BvHead r = ((const BvHead*)table)[idx[u]];
                 acc += r.word ^ r.prefix;
             } else if (ELEM == 8) {
                 acc += ((const uint64_t*)table)[idx[u]];
@@ -628,6 +654,10 @@ hipError_t launch_build_keyrecs(const uint64_t* checker, const uint32_t* tf, uin
 hipError_t launch_extract_tf(const KeyRec* recs, uint64_t n, uint32_t* tf, uint64_t* checker, hipStream_t s) {
     if (n == 0) return hipSuccess;
     AIX_LAUNCH(k_extract, n, s, recs, n, tf, checker);
+}
+hipError_t launch_set_fingerprints(const MphfDev& m, BvRec* recs_rw, const KeyRec* keys, uint64_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    AIX_LAUNCH(k_set_fp, n, s, m, recs_rw, keys, n);
 }
 hipError_t launch_scatter23(const MphfDev& m, uint64_t n, const uint8_t* keys, const uint64_t* codes, const uint32_t* counts, uint64_t* checker, uint32_t* tf,
                             uint32_t* occupied, uint32_t* conflict, hipStream_t s) {

@@ -143,6 +143,9 @@ class Index:
     def set_canonical_fastpath(self, enabled: bool):
         check(lib().aix_index_set_canonical_fastpath(self._h, int(enabled)))
 
+    def set_fingerprint_filter(self, enabled: bool):
+        check(lib().aix_index_set_fingerprint_filter(self._h, int(enabled)))
+
     def set_tf_13(self, tf: np.ndarray):
         tf = np.ascontiguousarray(tf, dtype=np.uint64)
         assert tf.shape[0] == _lib.TOTAL_13MERS

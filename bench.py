@@ -172,6 +172,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=2_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fastpath", action="store_true", help="force the reference's two-probe order")
+    ap.add_argument("--no-fingerprint", action="store_true", help="disable the 4-bit fingerprint filter")
     a = ap.parse_args()
 
     import torch
@@ -191,6 +192,8 @@ def main():
         ix, g, keys, counts, pf = build_index23(a.genome, rank, world, dev, cache)
         if a.no_fastpath:
             ix.set_canonical_fastpath(False)
+        if a.no_fingerprint:
+            ix.set_fingerprint_filter(False)
         q = engine.synth_kmers_t(7, a.queries, 23, dev, first=rank * a.queries)
         res = torch.empty(a.queries, dtype=torch.int32, device=f"cuda:{dev}")
         step = lambda: ix.tf_ascii_t(q, res)

@@ -85,6 +85,8 @@ int aix_index_close(aix_index_t* h);                  /* ~AindexWrapper, python_
 int aix_index_info(const aix_index_t* h, aix_info_t* info);
 /* force the two-probe path even on an all-canonical index (A/B measurements) */
 int aix_index_set_canonical_fastpath(aix_index_t* h, int enabled);
+/* switch the 4-bit fingerprint filter of the MPHF records off/on (A/B measurements; answers are identical) */
+int aix_index_set_fingerprint_filter(aix_index_t* h, int enabled);
 /* replace the tf table of a 13-mer handle (u64[4^13], mphf order, HOST pointer) */
 int aix_index_set_tf_13(aix_index_t* h, const uint64_t* tf);
 /* copy tf out (HOST pointer): 23 -> u32[n]; 13 -> u64[4^13] in mphf order

@@ -464,3 +464,46 @@ def test_kmer_counter_sets_golden(gold):
     keys, counts = counting.count_distinct(fa, 17, _lib.CANON_NONE, 1)
     okeys, ocnt = O.count_distinct(fa, 17, 0, 1)
     assert np.array_equal(keys, okeys) and np.array_equal(counts, ocnt)
+
+
+# ------------------------------------------------------------------------------------------------
+# fingerprint filter: identical answers on/off, also on an index whose files are inconsistent
+# ------------------------------------------------------------------------------------------------
+def test_fingerprint_filter_on_off(canon_case):
+    ix, orc = canon_case["ix"], canon_case["orc"]
+    q = mixed_queries(canon_case["genome"], 300_000, 21)
+    want = orc.tf_batch(q, threads=8)
+    for fast in (True, False):
+        ix.set_canonical_fastpath(fast)
+        for fp in (True, False):
+            ix.set_fingerprint_filter(fp)
+            assert np.array_equal(ix.tf_ascii(q), want), (fast, fp)
+    ix.set_canonical_fastpath(True)
+    ix.set_fingerprint_filter(True)
+
+
+def test_inconsistent_index_files_match_reference_semantics(canon_case, tmp_path):
+    """checker/tf that do not agree with the MPHF (swapped / foreign entries): same answers as the oracle."""
+    prefix = canon_case["prefix"]
+    checker = np.fromfile(prefix + ".kmers.bin", dtype=np.uint64)
+    tf = np.fromfile(prefix + ".tf.bin", dtype=np.uint32)
+    checker[[0, 1]] = checker[[1, 0]]
+    foreign = int(synth.sm64(77, np.array([0], dtype=np.uint64))[0]) & (4 ** 23 - 1)
+    victim = int(checker[5])
+    checker[5] = foreign
+    p2 = str(tmp_path / "bad")
+    checker.tofile(p2 + ".kmers.bin")
+    tf.tofile(p2 + ".tf.bin")
+    import shutil
+    shutil.copy(prefix + ".pf", p2 + ".pf")
+    orc = O.OracleIndex23.from_prefix(p2)
+    codes = np.array([int(checker[0]), int(checker[1]), foreign, victim] + [int(c) for c in checker[100:2100]], dtype=np.uint64)
+    codes = np.concatenate([codes, synth.revcomp_codes(codes, 23)])
+    q = synth.decode_kmers(codes, 23)
+    with Index.open_23(p2 + ".pf", p2 + ".tf.bin", p2 + ".kmers.bin") as ix:
+        want = orc.tf_batch(q)
+        for fp in (True, False):
+            ix.set_fingerprint_filter(fp)
+            assert np.array_equal(ix.tf_ascii(q), want)
+            kid, strand = ix.kid_strand_ascii(q)
+            assert strand.tolist() == [orc.strand(bytes(s)) for s in q]
