@@ -75,6 +75,7 @@ SIGNATURES = {
     "aix_count13_dev": (i32, [vp, vp, u64, vp, vp]),
     "aix_count23_fixed": (i32, [vp, vp, u64, i32, i32, vp]),
     "aix_count23_fixed_dev": (i32, [vp, vp, u64, i32, vp, vp]),
+    "aix_count_distinct": (i32, [vp, u64, i32, i32, i32, u64, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]),
     "aix_positions_fill": (i32, [vp, vp, u64, vp, vp, u64, C.POINTER(u64)]),
     "aix_window_codes_dev": (i32, [vp, u64, i32, i32, vp, vp]),
     "aix_normalize_reads": (i32, [vp, u64, i32, i32, vp, C.POINTER(u64)]),

@@ -53,9 +53,17 @@ def count_distinct_t(plain_t, k: int, canon_mode: int = _lib.CANON_TRUE_RC, min_
 
 def count_distinct(buf: bytes, k: int, canon_mode: int = _lib.CANON_TRUE_RC, min_count: int = 1, fmt: int = _lib.FMT_FASTA,
                    device: int = 0):
-    """kmer_counter replacement for a host buffer. Returns (keys uint64, counts uint64) sorted by key."""
-    import torch
-    plain = normalize(buf, fmt, 1)
-    t = torch.frombuffer(bytearray(plain) if plain else bytearray(1), dtype=torch.uint8)[: len(plain)].to(f"cuda:{device}")
-    keys, counts = count_distinct_t(t, k, canon_mode, min_count)
-    return keys.cpu().numpy().view(np.uint64), counts.cpu().numpy().astype(np.uint64)
+    """kmer_counter replacement for a host buffer, entirely behind the C ABI (aix_count_distinct: HIP window kernel +
+    rocPRIM sort / run-length). Returns (keys uint64, counts uint64) sorted by key."""
+    a = np.frombuffer(buf, dtype=np.uint8)
+    kp, cp, n = vp(), vp(), C.c_uint64()
+    check(lib().aix_count_distinct(a.ctypes.data_as(vp), a.shape[0], fmt, k, canon_mode, min_count, device, C.byref(kp), C.byref(cp), C.byref(n)),
+          "aix_count_distinct")
+    try:
+        m = n.value
+        keys = np.ctypeslib.as_array(C.cast(kp, C.POINTER(C.c_uint64)), shape=(max(m, 1),))[:m].copy()
+        counts = np.ctypeslib.as_array(C.cast(cp, C.POINTER(C.c_uint64)), shape=(max(m, 1),))[:m].copy()
+    finally:
+        lib().aix_free(kp)
+        lib().aix_free(cp)
+    return keys, counts

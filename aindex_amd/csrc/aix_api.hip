@@ -74,7 +74,7 @@ struct aix_index {
         d.m.recs = recs;
         d.m.D = D;
         d.m.seed = seed;
-        d.m.nrecs = W;
+        d.m.nrecs = (B + 15) / 16;
         d.m.fm = make_fastmod(D);
         d.keys = keys;
         d.n = n;
@@ -156,17 +156,18 @@ static int upload_mphf(aix_index* h, const uint8_t* pf, uint64_t len) {
     if (len < 32 + 8 * (h->W + R)) return AIX_ERR_FORMAT;
     if (h->mphf_n >> 32) return AIX_ERR_UNSUPPORTED;          // 32-bit rank prefixes
     const uint64_t* words = (const uint64_t*)(pf + 32);
+    const uint64_t nrec = (h->B + 15) / 16;                      // two records per 64-bit word
     std::vector<BvRec> recs;
-    try { recs.resize(h->W ? h->W : 1); } catch (const std::bad_alloc&) { return AIX_ERR_NOMEM; }
+    try { recs.resize(nrec ? nrec : 1); } catch (const std::bad_alloc&) { return AIX_ERR_NOMEM; }
     uint64_t run = 0;
-    for (uint64_t i = 0; i < h->W; ++i) {
+    for (uint64_t i = 0; i < nrec; ++i) {
         uint64_t w;
-        memcpy(&w, words + i, 8);
-        recs[i].word = w;
+        memcpy(&w, words + (i >> 1), 8);
+        const uint32_t half = (uint32_t)(w >> (32 * (i & 1)));
+        recs[i].pairs = half;
         recs[i].prefix = (uint32_t)run;
-        recs[i].pad = 0;
-        recs[i].fp[0] = recs[i].fp[1] = recs[i].fp[2] = recs[i].fp[3] = 0;
-        run += popc_pairs(w);
+        recs[i].fp = 0;
+        run += (uint32_t)__builtin_popcount((half | (half >> 1)) & 0x55555555u);
     }
     if (run >> 32) return AIX_ERR_UNSUPPORTED;
     const uint64_t bytes = sizeof(BvRec) * recs.size();
@@ -909,5 +910,43 @@ extern "C" int aix_positions_fill(aix_index_t* h, const char* reads, uint64_t le
     HIPCHK(hipMemset(dpos.p, 0, 8 * total));
     HIPCHK(positions_fill(h->dev(), (const uint8_t*)dreads.p, len, a2_start(reads, len), (const uint64_t*)dind.p, (uint64_t*)dpos.p, 0));
     HIPCHK(hipMemcpy(positions_out, dpos.p, 8 * total, hipMemcpyDeviceToHost));
+    return AIX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1: distinct canonical k-mers of a sequence file (kmer_counter replacement)
+// ---------------------------------------------------------------------------------------------
+extern "C" int aix_count_distinct(const char* buf, uint64_t len, int format, int k, int canon_mode, uint64_t min_count, int device, uint64_t** keys_out,
+                                  uint64_t** counts_out, uint64_t* n_out) {
+    if (!keys_out || !counts_out || !n_out || (len && !buf) || k < 1 || k > 31 || canon_mode < 0 || canon_mode > 2) return AIX_ERR_ARG;
+    *keys_out = nullptr; *counts_out = nullptr; *n_out = 0;
+    if (len >> 32) return AIX_ERR_UNSUPPORTED;
+    int st = check_device(device);
+    if (st) return st;
+    DevGuard g(device);
+    DevBuf d, dcodes;
+    uint64_t plen = 0;
+    st = stage_plain(nullptr, buf, len, format, 1, d, plen);
+    if (st) return st;
+    if (plen < (uint64_t)k) return AIX_OK;
+    const uint64_t nwin = plen - k + 1;
+    HIPCHK(dcodes.alloc(8 * nwin));
+    HIPCHK(launch_window_codes((const uint8_t*)d.p, plen, k, canon_mode, (uint64_t*)dcodes.p, 0));
+    uint64_t* dk = nullptr; uint32_t* dc = nullptr; uint64_t m = 0;
+    HIPCHK(distinct_from_codes((uint64_t*)dcodes.p, nwin, k, min_count ? min_count : 1, &dk, &dc, &m, 0));
+    uint64_t* hk = (uint64_t*)malloc(8 * (m ? m : 1));
+    uint64_t* hc = (uint64_t*)malloc(8 * (m ? m : 1));
+    std::vector<uint32_t> c32(m);
+    hipError_t e = hipSuccess;
+    if (!hk || !hc) { free(hk); free(hc); if (dk) (void)hipFree(dk); if (dc) (void)hipFree(dc); return AIX_ERR_NOMEM; }
+    if (m) {
+        e = hipMemcpy(hk, dk, 8 * m, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(c32.data(), dc, 4 * m, hipMemcpyDeviceToHost);
+    }
+    if (dk) (void)hipFree(dk);
+    if (dc) (void)hipFree(dc);
+    if (e != hipSuccess) { free(hk); free(hc); set_last_error(std::string("count_distinct: ") + hipGetErrorString(e)); return AIX_ERR_HIP; }
+    for (uint64_t i = 0; i < m; ++i) hc[i] = c32[i];
+    *keys_out = hk; *counts_out = hc; *n_out = m;
     return AIX_OK;
 }

@@ -19,22 +19,17 @@ namespace aix {
 // ---------------------------------------------------------------------------------------------
 // HBM layouts
 // ---------------------------------------------------------------------------------------------
-// One record per 64-bit word of the emphf bit-pair vector: the word itself plus the number of
-// non-zero pairs in all words before it. rank(pos) = prefix + popc_pairs(word & mask(pos)), so a
-// lookup needs exactly three independent 16-byte reads and no dependent rank-directory read.
-// The second half holds a 4-bit fingerprint per bit-pair position: the fingerprint of the key whose assigned
-// (hidx-selected) node is that position. A probe whose fingerprint differs from the stored one cannot match
-// checker[rank] and is answered "absent" without touching the key table (15/16 of all misses).
-struct __attribute__((aligned(16))) BvHead {
-    uint64_t word;
+// One 16-byte record per 16 bit-pairs (half a word of the emphf bit-pair vector): the 16 pairs, the number of
+// non-zero pairs in everything before them, and a 4-bit fingerprint per pair position.
+//   rank(pos) = prefix + popc_pairs(pairs & mask(pos))            (ranked_bitpair_vector.hpp:47-62)
+// so one MPHF evaluation is exactly three independent 16-byte reads and no dependent rank-directory read.
+// fp nibble j = fingerprint of the key whose assigned (hidx-selected) node is pair j (0 if none): a probe whose
+// fingerprint differs from the stored one cannot match checker[rank] and is answered "absent" without touching
+// the key table (15/16 of all misses).
+struct __attribute__((aligned(16))) BvRec {
+    uint32_t pairs;      // 16 x 2 bits
     uint32_t prefix;
-    uint32_t pad;
-};
-struct __attribute__((aligned(32))) BvRec {
-    uint64_t word;
-    uint32_t prefix;
-    uint32_t pad;
-    uint32_t fp[4];      // 32 x 4 bits, nibble j = fingerprint of the key assigned to pair j (0 if none)
+    uint64_t fp;         // 16 x 4 bits
 };
 // checker[] and tf[] of PHASH_MAP (hash.hpp:82-121) interleaved: one 16-byte read per probe.
 struct __attribute__((aligned(16))) KeyRec {
@@ -267,54 +262,38 @@ struct MphfDev {
     const BvRec* recs;   // W records
     uint64_t D;          // hash domain
     uint64_t seed;
-    uint64_t nrecs;      // W
+    uint64_t nrecs;      // ceil(B/16)
     FastMod fm;
 };
 
-__device__ __forceinline__ BvHead load_head(const BvRec* recs, uint64_t i) { return *(const BvHead*)(recs + i); }
-
-// 4-bit fingerprint of a key, taken from hash bits that the node computation does not expose
+// 4-bit fingerprint of a key, from hash bits that the node computation does not expose
 __device__ __forceinline__ uint32_t fp_of_hash(uint64_t a, uint64_t b, uint64_t c) { return (uint32_t)((a ^ b ^ c) >> 60); }
 
-// mphf::lookup plus the stored fingerprint of the selected node and the node itself
+// mphf::lookup (mphf.hpp:79-89) plus the stored fingerprint of the selected node and the node itself
 __device__ __forceinline__ uint64_t mphf_from_hash_fp(const MphfDev& m, uint64_t a, uint64_t b, uint64_t c, uint32_t& fp_stored, uint64_t& node) {
     const uint64_t n0 = fastmod(a, m.fm);
     const uint64_t n1 = m.D + fastmod(b, m.fm);
     const uint64_t n2 = 2 * m.D + fastmod(c, m.fm);
-    const BvHead r0 = load_head(m.recs, n0 >> 5);
-    const BvHead r1 = load_head(m.recs, n1 >> 5);
-    const BvHead r2 = load_head(m.recs, n2 >> 5);
-    // the three candidate fingerprint dwords are read up front, next to their heads (same 32-byte record, no new
-    // line). Measured: 17.5 G lookups/s this way vs 16.4 G/s with one dependent read after hidx is known.
-    const uint32_t f0 = m.recs[n0 >> 5].fp[(n0 & 31) >> 3];
-    const uint32_t f1 = m.recs[n1 >> 5].fp[(n1 & 31) >> 3];
-    const uint32_t f2 = m.recs[n2 >> 5].fp[(n2 & 31) >> 3];
-    const uint32_t s0 = (uint32_t)(n0 & 31) * 2, s1 = (uint32_t)(n1 & 31) * 2, s2 = (uint32_t)(n2 & 31) * 2;
-    const uint32_t v = (uint32_t)((r0.word >> s0) & 3) + (uint32_t)((r1.word >> s1) & 3) + (uint32_t)((r2.word >> s2) & 3);
-    const uint32_t hidx = v - 3u * ((v * 11u) >> 5);
-    const uint64_t w = hidx == 0 ? r0.word : (hidx == 1 ? r1.word : r2.word);
+    const BvRec r0 = m.recs[n0 >> 4];
+    const BvRec r1 = m.recs[n1 >> 4];
+    const BvRec r2 = m.recs[n2 >> 4];
+    const uint32_t s0 = (uint32_t)(n0 & 15) * 2, s1 = (uint32_t)(n1 & 15) * 2, s2 = (uint32_t)(n2 & 15) * 2;
+    const uint32_t v = ((r0.pairs >> s0) & 3) + ((r1.pairs >> s1) & 3) + ((r2.pairs >> s2) & 3);
+    const uint32_t hidx = v - 3u * ((v * 11u) >> 5);               // v in 0..9 -> v % 3
+    const uint32_t w = hidx == 0 ? r0.pairs : (hidx == 1 ? r1.pairs : r2.pairs);
     const uint32_t p = hidx == 0 ? r0.prefix : (hidx == 1 ? r1.prefix : r2.prefix);
     const uint32_t sh = hidx == 0 ? s0 : (hidx == 1 ? s1 : s2);
+    const uint64_t f = hidx == 0 ? r0.fp : (hidx == 1 ? r1.fp : r2.fp);
     node = hidx == 0 ? n0 : (hidx == 1 ? n1 : n2);
-    const uint32_t f = hidx == 0 ? f0 : (hidx == 1 ? f1 : f2);
-    fp_stored = (f >> ((sh & 15) * 2)) & 15u;                      // nibble (node & 7) of the dword: sh = 2*(node & 31)
-    return (uint64_t)p + popc_pairs(w & ((1ULL << sh) - 1));
+    fp_stored = (uint32_t)(f >> (sh * 2)) & 15u;                   // nibble (node & 15)
+    const uint32_t below = w & ((1u << sh) - 1u);
+    return (uint64_t)p + (uint32_t)__builtin_popcount((below | (below >> 1)) & 0x55555555u);
 }
 
 __device__ __forceinline__ uint64_t mphf_from_hash(const MphfDev& m, uint64_t a, uint64_t b, uint64_t c) {
-    const uint64_t n0 = fastmod(a, m.fm);
-    const uint64_t n1 = m.D + fastmod(b, m.fm);
-    const uint64_t n2 = 2 * m.D + fastmod(c, m.fm);
-    const BvHead r0 = load_head(m.recs, n0 >> 5);
-    const BvHead r1 = load_head(m.recs, n1 >> 5);
-    const BvHead r2 = load_head(m.recs, n2 >> 5);
-    const uint32_t s0 = (uint32_t)(n0 & 31) * 2, s1 = (uint32_t)(n1 & 31) * 2, s2 = (uint32_t)(n2 & 31) * 2;
-    const uint32_t v = (uint32_t)((r0.word >> s0) & 3) + (uint32_t)((r1.word >> s1) & 3) + (uint32_t)((r2.word >> s2) & 3);
-    const uint32_t hidx = v - 3u * ((v * 11u) >> 5);               // v in 0..9 -> v % 3
-    const uint64_t w = hidx == 0 ? r0.word : (hidx == 1 ? r1.word : r2.word);
-    const uint32_t p = hidx == 0 ? r0.prefix : (hidx == 1 ? r1.prefix : r2.prefix);
-    const uint32_t sh = hidx == 0 ? s0 : (hidx == 1 ? s1 : s2);
-    return (uint64_t)p + popc_pairs(w & ((1ULL << sh) - 1));
+    uint32_t fps;
+    uint64_t node;
+    return mphf_from_hash_fp(m, a, b, c, fps, node);
 }
 
 }  // namespace aix

@@ -65,6 +65,10 @@ hipError_t positions_indices(const IndexDev& ix, uint64_t* d_indices /* n+1 */, 
 hipError_t positions_fill(const IndexDev& ix, const uint8_t* d_reads, uint64_t len, uint64_t start, const uint64_t* d_indices, uint64_t* d_positions,
                           hipStream_t s);
 
+// distinct k-mers = sort + run-length of window codes; outputs hipMalloc'd (caller frees), d_codes is clobbered
+hipError_t distinct_from_codes(uint64_t* d_codes, uint64_t nwin, int k, uint64_t min_count, uint64_t** d_keys_out, uint32_t** d_counts_out, uint64_t* n_out,
+                               hipStream_t s);
+
 // synthetic generators
 hipError_t launch_synth_genome(uint64_t seed, uint64_t length, uint8_t* out, hipStream_t s);
 hipError_t launch_synth_kmers(uint64_t seed, uint64_t first, uint64_t N, int k, uint8_t* out, hipStream_t s);

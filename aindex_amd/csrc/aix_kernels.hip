@@ -372,7 +372,7 @@ __global__ void __launch_bounds__(kBlock) k_set_fp(const MphfDev m, BvRec* __res
         ascii23_of_rc(revcomp(code, 23), w0, w1, w2);
         jenkins23(w0, w1, w2, m.seed, a, b, c);
         if (mphf_from_hash_fp(m, a, b, c, fps, node) != i) continue;
-        atomicOr(&recs[node >> 5].fp[(node & 31) >> 3], fp_of_hash(a, b, c) << (4 * (uint32_t)(node & 7)));
+        atomicOr((unsigned long long*)&recs[node >> 4].fp, (unsigned long long)fp_of_hash(a, b, c) << (4 * (uint32_t)(node & 15)));
     }
 }
 
@@ -583,8 +583,8 @@ __global__ void __launch_bounds__(kBlock) k_gather(const uint8_t* __restrict__ t
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             if (ELEM == 16) {
-                const BvHead r = ((const BvHead*)table)[idx[u]];
-                acc += r.word ^ r.prefix;
+                const BvRec r = ((const BvRec*)table)[idx[u]];
+                acc += r.fp ^ r.prefix;
             } else if (ELEM == 8) {
                 acc += ((const uint64_t*)table)[idx[u]];
             } else {

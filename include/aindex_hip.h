@@ -189,6 +189,12 @@ int aix_window_codes_dev(const char* d_plain, uint64_t len, int k, int canon_mod
  * slot order is schedule dependent). positions_out may be NULL to query *total_out = indices[n] first. len < 2^32. */
 int aix_positions_fill(aix_index_t* h, const char* reads, uint64_t len, uint64_t* indices_out, uint64_t* positions_out,
                        uint64_t positions_cap, uint64_t* total_out);
+/* K1 complete: replaces `kmer_counter <in.fa> <k> <out> [-t N] [-m min]` (src/count_kmers.cpp:235-382): the set of
+ * (canonical k-mer code, count) with count >= min_count, sorted by code ascending (the reference sorts by count with
+ * unspecified tie order; parity is on the set). *keys_out / *counts_out are malloc'd (aix_free). format as for the
+ * counters (FASTA records follow count_kmers.cpp:250-295). 1 <= k <= 31, len < 2^32, counts < 2^32. */
+int aix_count_distinct(const char* buf, uint64_t len, int format, int k, int canon_mode, uint64_t min_count, int device,
+                       uint64_t** keys_out, uint64_t** counts_out, uint64_t* n_out);
 /* Host-side record normalisation to PLAIN form (readers of count_kmers13.cpp:211-272 /
  * count_kmers.cpp:250-295): out must hold len+1 bytes; *out_len receives the normalised length.
  * fasta_mode: 0 = count_kmers13 rules, 1 = kmer_counter rules ('>' anywhere starts a record). */
