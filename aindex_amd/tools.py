@@ -4,6 +4,8 @@
     python -m aindex_amd.tools kmer_counter  <in.fa> <k> <out> [-t N] [-m min] [--canon refx86|true|none]
     python -m aindex_amd.tools compute_mphf_seq <keys.txt> [out.pf]
     python -m aindex_amd.tools compute_index <dat> <pf> <prefix> <threads> <mock>
+    python -m aindex_amd.tools compute_aindex <reads> <pf> <prefix> <threads> 23 <tf> <kmers.bin> <kmers.txt> [index.bin indices.bin]
+    python -m aindex_amd.tools compute_reads <file1> <file2|-> <fastq|fasta|se|reads> <prefix>     (host-side, no GPU)
 
 `threads` arguments are accepted and ignored (the work runs on the GPU). Exit status 0 on success.
 """
@@ -97,7 +99,122 @@ def compute_index(argv) -> int:
     return 0
 
 
-COMMANDS = {"count_kmers13": count_kmers13, "kmer_counter": kmer_counter, "compute_mphf_seq": compute_mphf_seq, "compute_index": compute_index}
+def compute_reads(argv) -> int:
+    """compute_reads.cpp:20-216: <file1> <file2|-> <fastq|fasta|se|reads> <output_prefix> -> .reads / .ridx / .header.
+    Host-side text reformatting exactly as the reference (I/O bound; no device work)."""
+    if len(argv) < 4:
+        print("Expected arguments: compute_reads <fastq_file1|fasta_file1|reads_file> <fastq_file2|-> <fastq|fasta|se|reads> <output_prefix>",
+              file=sys.stderr)
+        return 1
+    f1, f2, mode, prefix = argv[:4]
+    import os
+    d = os.path.dirname(prefix)
+    if d:
+        os.makedirs(d, exist_ok=True)
+
+    def lines(path):
+        data = open(path, "rb").read()
+        out = data.split(b"\n")
+        if out and out[-1] == b"":
+            out.pop()                      # std::getline yields no empty line after a trailing newline
+        return out
+
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+
+    def revcomp(s: bytes) -> bytes:        # get_revcomp(const std::string&), kmers.cpp:310-330: others -> 'N'
+        return bytes(c if c in b"ACGT" else 78 for c in s[::-1]).translate(comp)
+
+    reads, ridx, header = [], [], []
+    start = 0
+    n = 0
+    if mode == "fastq":                    # :77-116 R1~revcomp(R2)
+        a, b = lines(f1), lines(f2)
+        i = 0
+        while i < len(a):                  # while getline(fin1) [header] ; then sequence lines, then 2 more lines each
+            l1 = a[i + 1] if i + 1 < len(a) else b""
+            l2 = b[i + 1] if i + 1 < len(b) else b""
+            end = start + len(l1) + len(l2) + 1
+            reads.append(l1 + b"~" + revcomp(l2) + b"\n")
+            ridx.append(b"%d\t%d\t%d\n" % (n, start, end))
+            start = end + 1
+            n += 1
+            i += 4
+    elif mode == "se":                     # :118-147
+        a = lines(f1)
+        i = 0
+        while i < len(a):
+            l1 = a[i + 1] if i + 1 < len(a) else b""
+            end = start + len(l1)
+            reads.append(l1 + b"\n")
+            ridx.append(b"%d\t%d\t%d\n" % (n, start, end))
+            start = end + 1
+            n += 1
+            i += 4
+    elif mode == "reads":                  # :149-168: index only
+        for l1 in lines(f1):
+            end = start + len(l1)
+            ridx.append(b"%d\t%d\t%d\n" % (n, start, end))
+            start = end + 1
+            n += 1
+        reads = None
+    elif mode == "fasta":                  # :170-213
+        cur, head = b"", b""
+
+        def flush():
+            nonlocal start, n, cur
+            end = start + len(cur)
+            reads.append(cur + b"\n")
+            ridx.append(b"%d\t%d\t%d\n" % (n, start, end))
+            header.append(head + b"\t%d\t%d\n" % (start, len(cur)))
+            start = end + 1
+            n += 1
+            cur = b""
+
+        for l1 in lines(f1):
+            if l1[:1] == b">":             # line1[0] == '>' (an empty line reads the terminating NUL: not '>')
+                if cur:
+                    flush()
+                head = l1[1:]
+                continue
+            cur += l1
+        if cur:
+            flush()
+    else:
+        print("Unknown format.", file=sys.stderr)
+        return 2
+    if reads is not None:
+        with open(prefix + ".reads", "wb") as f:
+            f.write(b"".join(reads))
+    with open(prefix + ".ridx", "wb") as f:
+        f.write(b"".join(ridx))
+    if mode == "fasta":
+        with open(prefix + ".header", "wb") as f:
+            f.write(b"".join(header))
+    return 0
+
+
+def compute_aindex(argv) -> int:
+    """compute_aindex.cpp:28-116: <reads> <pf> <prefix> <threads> <k> <tf> <kmers.bin> <kmers.txt> [..index.bin] [..indices.bin]
+    (the reference reads argv[10]/argv[11] for the optional names, :61-62)."""
+    if len(argv) < 7:
+        print("Expected arguments: compute_aindex <reads_file> <hash_file> <output_prefix> <num_threads> <k> <tf_file> <kmers_bin_file> "
+              "<kmers_text_file> [index_bin] [indices_bin]", file=sys.stderr)
+        return 1
+    reads_file, pf, prefix, _threads, k, tf_file, kmers_bin = argv[:7]
+    if int(k) != 23:
+        print("compute_aindex: only k = 23 is supported (the 13-mer branch of the reference is inconsistent, SURVEY row 9)", file=sys.stderr)
+        return 1
+    index_bin = argv[9] if len(argv) > 9 else prefix + ".index.bin"
+    indices_bin = argv[10] if len(argv) > 10 else prefix + ".indices.bin"
+    with Index.open_23(pf, tf_file, kmers_bin) as ix:
+        indices, pos = ix.positions_fill(open(reads_file, "rb").read())
+    pos.tofile(index_bin)
+    indices.tofile(indices_bin)
+    return 0
+
+
+COMMANDS = {"count_kmers13": count_kmers13, "kmer_counter": kmer_counter, "compute_mphf_seq": compute_mphf_seq, "compute_index": compute_index,
+            "compute_reads": compute_reads, "compute_aindex": compute_aindex}
 
 
 def main(argv=None) -> int:

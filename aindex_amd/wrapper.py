@@ -180,10 +180,27 @@ class AindexWrapper:
     def get_tf_value(self, kmer: str) -> int:
         return self.get_tf_values([kmer])[0]                                            # :644-651
 
+    @staticmethod
+    def _join_fixed(kmers, k: int):
+        """One bytes object of len(kmers)*k bytes when every item is a k-character str/bytes, else None."""
+        try:
+            if isinstance(kmers[0], str):
+                flat = "".join(kmers).encode("latin-1")
+            else:
+                flat = b"".join(kmers)
+        except (TypeError, UnicodeEncodeError):
+            return None
+        if len(flat) != k * len(kmers) or any(len(s) != k for s in kmers):
+            return None
+        return flat
+
     def get_tf_values_23mer(self, kmers: List[str]) -> List[int]:
         if not kmers:
             return []
-        return self._need23().tf_ragged(kmers).tolist()                                 # :1219-1228
+        flat = self._join_fixed(kmers, 23)                                              # common case: all 23-mers
+        if flat is not None:
+            return self._need23().tf_ascii(flat).tolist()
+        return self._need23().tf_ragged(kmers).tolist()                                 # :1219-1228, any lengths
 
     def get_tf_value_23mer(self, kmer: str) -> int:
         return self.get_tf_values_23mer([kmer])[0]
@@ -194,6 +211,9 @@ class AindexWrapper:
             return [0] * len(kmers)
         if not kmers:
             return []
+        flat = self._join_fixed(kmers, 13)
+        if flat is not None:
+            return self._ix13.tf_ascii(flat).tolist()
         return self._ix13.tf_ragged(kmers).tolist()
 
     def get_tf_value_13mer(self, kmer: str) -> int:

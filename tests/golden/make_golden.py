@@ -349,6 +349,32 @@ def make_count13(pf):
     print("q13 queries", len(q), "nonzero", sum(1 for x in exp["tf"] if x))
 
 
+def make_compute_reads():
+    """N4: compute_reads outputs (.reads/.ridx/.header) for every input mode, on the reference's own tiny inputs."""
+    d = os.path.join(GOLD, "compute_reads")
+    os.makedirs(d, exist_ok=True)
+    w = os.path.join(TMP, "compute_reads")
+    shutil.rmtree(w, ignore_errors=True)
+    os.makedirs(w)
+    cases = {
+        "pe": (os.path.join(REFDATA, "test_R1.fastq"), os.path.join(REFDATA, "test_R2.fastq"), "fastq"),
+        "se": (os.path.join(REFDATA, "test_se.fastq"), "-", "se"),
+        "fasta": (os.path.join(REFDATA, "test.fasta"), "-", "fasta"),
+        "reads": (os.path.join(REFDATA, "test_reads.txt"), "-", "reads"),
+        "fasta_multi": (os.path.join(GOLD, "count13", "synth.fa"), "-", "fasta"),
+    }
+    for name, (f1, f2, mode) in cases.items():
+        for f in (f1, f2):
+            if f != "-" and not f.startswith(GOLD):
+                shutil.copy(f, os.path.join(d, "in_" + os.path.basename(f)))
+        run([os.path.join(REF, "compute_reads"), f1, f2, mode, os.path.join(w, name)])
+        for ext in (".reads", ".ridx", ".header"):
+            src = os.path.join(w, name + ext)
+            if os.path.exists(src):
+                shutil.copy(src, os.path.join(d, name + ext))
+        print("compute_reads", name, [e for e in (".reads", ".ridx", ".header") if os.path.exists(os.path.join(w, name + e))])
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-13mer-pf", action="store_true", help="reuse data/all_13mers.pf if present")
@@ -364,6 +390,8 @@ if __name__ == "__main__":
         make_small23()
     if not only or "kmer_counter" in only:
         make_kmer_counter()
+    if not only or "compute_reads" in only:
+        make_compute_reads()
     if not only or "13" in only:
         pf = make_pf13(a.skip_13mer_pf)
         make_count13(pf)

@@ -507,3 +507,40 @@ def test_inconsistent_index_files_match_reference_semantics(canon_case, tmp_path
             assert np.array_equal(ix.tf_ascii(q), want)
             kid, strand = ix.kid_strand_ascii(q)
             assert strand.tolist() == [orc.strand(bytes(s)) for s in q]
+
+
+# ------------------------------------------------------------------------------------------------
+# edge cases: empty / tiny / boundary inputs
+# ------------------------------------------------------------------------------------------------
+def test_edge_cases(ix23, ix13, canon_case, small23_prefix):
+    orc = O.OracleIndex23.from_prefix(small23_prefix)
+    assert ix23.tf_ascii(b"").shape == (0,)
+    assert ix23.tf_ragged([]).shape == (0,)
+    assert ix23.coverage([]) == []
+    assert [c.shape[0] for c in ix23.coverage(["", "A" * 22, "A" * 23])] == [0, 0, 1]
+    one = open(small23_prefix + ".dat").read().split("\t")[0]
+    assert ix23.tf_ascii(one.encode()).tolist() == [orc.tf(one.encode())]
+    for buf in (b"", b"A", b"ACGT" * 5, b"\n\n\n", b"ACGTACGTACGTACGTACGTACG", b"ACGTACGTACGTACGTACGTACG\n"):
+        for mode in (0, 1, 2):
+            assert np.array_equal(ix23.count23_fixed(buf, _lib.FMT_PLAIN, mode), orc.count23_fixed(buf, False, mode))
+        ind, pos = ix23.positions_fill(buf)
+        oind, opos = orc.positions(buf)
+        assert np.array_equal(ind, oind) and np.array_equal(pos, opos)
+    from pf13 import pf13_path
+    m = O.OracleMphf(pf13_path())
+    for buf in (b"", b"ACGT", b"ACGTACGTACGTA", b"ACGTACGTACGT\nA", b">h\nACGTACGTACGTA", b"@r\nACGTACGTACGTAC\n+\nIIIIIIIIIIIIII"):
+        assert np.array_equal(ix13.count13(buf), O.count13(m, buf, -1)), buf
+    assert ix13.tf_ragged(["", "A" * 13, "A" * 12, "A" * 14]).tolist()[0] == 0
+    from aindex_amd import counting
+    for buf in (b"", b">x\n", b">x\nACGT\n", b"no header ACGTACGTACGTACGTACGTACGTACGT\n"):
+        keys, counts = counting.count_distinct(buf, 23, _lib.CANON_REF_X86, 1)
+        okeys, ocnt = O.count_distinct(buf, 23, 1, 1)
+        assert np.array_equal(keys, okeys) and np.array_equal(counts, ocnt)
+    # wrapper list[str] fast path == ragged path
+    from aindex_amd.wrapper import AindexWrapper
+    w = AindexWrapper()
+    w.load_from_prefix_23mer(small23_prefix)
+    q = [one, one[:-1] + "N", "ACGT", one + "A"]
+    assert w.get_tf_values(q) == [orc.tf(s.encode()) for s in q]
+    assert w.get_tf_values([one, one]) == [orc.tf(one.encode())] * 2
+    w.close()
