@@ -61,8 +61,10 @@ def count_distinct(buf: bytes, k: int, canon_mode: int = _lib.CANON_TRUE_RC, min
           "aix_count_distinct")
     try:
         m = n.value
-        keys = np.ctypeslib.as_array(C.cast(kp, C.POINTER(C.c_uint64)), shape=(max(m, 1),))[:m].copy()
-        counts = np.ctypeslib.as_array(C.cast(cp, C.POINTER(C.c_uint64)), shape=(max(m, 1),))[:m].copy()
+        if m == 0 or not kp.value or not cp.value:
+            return np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.uint64)
+        keys = np.ctypeslib.as_array(C.cast(kp, C.POINTER(C.c_uint64)), shape=(m,)).copy()
+        counts = np.ctypeslib.as_array(C.cast(cp, C.POINTER(C.c_uint64)), shape=(m,)).copy()
     finally:
         lib().aix_free(kp)
         lib().aix_free(cp)
