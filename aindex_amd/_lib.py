@@ -79,6 +79,7 @@ SIGNATURES = {
     "aix_positions_fill": (i32, [vp, vp, u64, vp, vp, u64, C.POINTER(u64)]),
     "aix_window_codes_dev": (i32, [vp, u64, i32, i32, vp, vp]),
     "aix_normalize_reads": (i32, [vp, u64, i32, i32, vp, C.POINTER(u64)]),
+    "aix_normalize_reads_dev": (i32, [vp, u64, i32, i32, vp, C.POINTER(u64), vp]),
     "aix_detect_format": (i32, [vp, u64]),
     "aix_synth_genome_dev": (i32, [u64, u64, vp, vp]),
     "aix_synth_kmers_dev": (i32, [u64, u64, u64, i32, vp, vp]),

@@ -27,6 +27,18 @@ def normalize(buf: bytes, fmt: int = _lib.FMT_AUTO, fasta_mode: int = 1) -> byte
     return out[: n.value].tobytes()
 
 
+def normalize_t(raw_t, fmt: int, fasta_mode: int = 1):
+    """Device-side record normalisation: uint8 tensor of raw FASTA/FASTQ bytes in HBM -> PLAIN uint8 tensor."""
+    import torch
+    n = raw_t.numel()
+    out = torch.empty(n + 16, dtype=torch.uint8, device=raw_t.device)
+    m = C.c_uint64()
+    with torch.cuda.device(raw_t.device):
+        check(lib().aix_normalize_reads_dev(vp(raw_t.data_ptr()), n, fmt, fasta_mode, vp(out.data_ptr()), C.byref(m),
+                                            vp(torch.cuda.current_stream().cuda_stream)), "aix_normalize_reads_dev")
+    return out[: m.value]
+
+
 def window_codes_t(plain_t, k: int, canon_mode: int):
     """int64 tensor (u64 bit patterns) of len-k+1 canonical window codes; -1 (= ~0) marks invalid windows."""
     import torch

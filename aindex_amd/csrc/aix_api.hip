@@ -816,21 +816,34 @@ extern "C" int aix_normalize_reads(const char* buf, uint64_t len, int format, in
     return AIX_OK;
 }
 
-static int stage_plain(aix_index_t* h, const char* buf, uint64_t len, int format, int fasta_mode, DevBuf& d, uint64_t& plain_len) {
-    if (format == AIX_FMT_AUTO) format = aix_detect_format(buf, len);
-    const char* src = buf;
-    std::vector<char> tmp;
-    plain_len = len;
-    if (format != AIX_FMT_PLAIN) {
-        try { tmp.resize(len + 2); } catch (const std::bad_alloc&) { return AIX_ERR_NOMEM; }
-        int st = aix_normalize_reads(buf, len, format, fasta_mode, tmp.data(), &plain_len);
-        if (st) return st;
-        src = tmp.data();
+extern "C" int aix_normalize_reads_dev(const char* d_raw, uint64_t len, int format, int fasta_mode, char* d_out, uint64_t* out_len, void* stream) {
+    if (!out_len || (len && (!d_raw || !d_out))) return AIX_ERR_ARG;
+    if (format != AIX_FMT_PLAIN && format != AIX_FMT_FASTA && format != AIX_FMT_FASTQ) return AIX_ERR_ARG;   // no auto-detect on device buffers
+    if (format == AIX_FMT_PLAIN) {
+        if (len) HIPCHK(hipMemcpyAsync(d_out, d_raw, len, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+        *out_len = len;
+        return AIX_OK;
     }
-    HIPCHK(d.alloc(plain_len + 8));
-    if (plain_len) HIPCHK(hipMemcpy(d.p, src, plain_len, hipMemcpyHostToDevice));
-    (void)h;
+    HIPCHK(normalise_device((const uint8_t*)d_raw, len, format, fasta_mode, (uint8_t*)d_out, out_len, (hipStream_t)stream));
     return AIX_OK;
+}
+
+// host buffer -> PLAIN form in HBM: raw bytes go up as they are, FASTA/FASTQ records are normalised on the device
+static int stage_plain(aix_index_t* h, const char* buf, uint64_t len, int format, int fasta_mode, DevBuf& d, uint64_t& plain_len) {
+    (void)h;
+    if (format == AIX_FMT_AUTO) format = aix_detect_format(buf, len);
+    plain_len = len;
+    if (format == AIX_FMT_PLAIN || len == 0) {
+        HIPCHK(d.alloc(len + 8));
+        if (len) HIPCHK(hipMemcpy(d.p, buf, len, hipMemcpyHostToDevice));
+        return AIX_OK;
+    }
+    DevBuf raw;
+    HIPCHK(raw.alloc(len + 8));
+    HIPCHK(hipMemcpy(raw.p, buf, len, hipMemcpyHostToDevice));
+    HIPCHK(d.alloc(len + 16));
+    return aix_normalize_reads_dev((const char*)raw.p, len, format, fasta_mode, (char*)d.p, &plain_len, nullptr);
 }
 
 extern "C" int aix_count13(aix_index_t* h, const char* buf, uint64_t len, int format, uint64_t* tf_out) {

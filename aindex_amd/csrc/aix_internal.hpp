@@ -69,6 +69,9 @@ hipError_t positions_fill(const IndexDev& ix, const uint8_t* d_reads, uint64_t l
 hipError_t distinct_from_codes(uint64_t* d_codes, uint64_t nwin, int k, uint64_t min_count, uint64_t** d_keys_out, uint32_t** d_counts_out, uint64_t* n_out,
                                hipStream_t s);
 
+// record normalisation on the device (aix_normalize.hip); d_out holds len + 1 bytes
+hipError_t normalise_device(const uint8_t* d_raw, uint64_t len, int format, int fasta_mode, uint8_t* d_out, uint64_t* out_len, hipStream_t s);
+
 // synthetic generators
 hipError_t launch_synth_genome(uint64_t seed, uint64_t length, uint8_t* out, hipStream_t s);
 hipError_t launch_synth_kmers(uint64_t seed, uint64_t first, uint64_t N, int k, uint8_t* out, hipStream_t s);

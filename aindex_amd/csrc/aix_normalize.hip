@@ -1,0 +1,221 @@
+// aix_normalize.hip — FASTA / FASTQ record normalisation to PLAIN form on the GPU.
+//
+// Same bytes as the host routine aix_normalize_reads (readers of count_kmers13.cpp:211-272 and
+// count_kmers.cpp:250-295). Each reader is a finite-state transducer over bytes with <= 8 states that emits at
+// most one byte per input byte (plus one '\n' at end of input), so the state at the start of every 256-byte chunk
+// comes from an exclusive scan of per-chunk transition FUNCTIONS (3 bits x 8 states packed in a u32, composed
+// associatively), and the output offset of every chunk from a second (sum) scan:
+//   k_norm_summarise : every chunk, simulated from all 8 start states at once -> transition function + emit counts
+//   rocPRIM scan #1  : function composition  -> true start state per chunk
+//   k_norm_pick      : emit count under the true start state
+//   rocPRIM scan #2  : output offsets
+//   k_norm_emit      : re-simulate from the true state and write the output (dword-packed stores)
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "../../include/aindex_hip.h"
+#include "aix_internal.hpp"
+
+namespace aix {
+
+static constexpr int NCH = 256;     // bytes per chunk
+static constexpr int NTB = 256;
+
+enum NormKind { NORM_FASTQ = 0, NORM_FASTA13 = 1, NORM_FASTAK1 = 2 };
+
+// One transducer step. Returns true when a byte is emitted (in `out`). States are 0..7.
+template <int KIND>
+__device__ __forceinline__ bool norm_step(uint32_t& st, uint32_t b, uint32_t& out) {
+    if (KIND == NORM_FASTQ) {
+        // st = (line_no & 3) | (nonempty << 2); count_kmers13.cpp:240-257: lines 4i+1, non-empty
+        const uint32_t ln = st & 3u;
+        if (b == '\n') {
+            const bool emit = (ln == 1u) && (st & 4u);
+            st = (ln + 1u) & 3u;
+            out = '\n';
+            return emit;
+        }
+        if (ln == 1u) { st |= 4u; out = b; return true; }
+        return false;
+    } else if (KIND == NORM_FASTA13) {
+        // st bit0 = at line start, bit1 = in header, bit2 = open (sequence bytes since the last separator)
+        // count_kmers13.cpp:211-235: empty lines skipped, '>' lines close the open record, others are appended
+        if (st & 1u) {
+            if (b == '\n') return false;                                   // empty line
+            if (b == '>') {
+                const bool emit = (st & 4u) != 0;
+                st = 2u;                                                   // in header, not open
+                out = '\n';
+                return emit;
+            }
+            st = 4u;                                                       // sequence line, open
+            out = b;
+            return true;
+        }
+        if (b == '\n') { st = (st & 4u) | 1u; return false; }
+        if (st & 2u) return false;
+        out = b;
+        return true;
+    } else {
+        // kmer_counter (count_kmers.cpp:250-295): st 0 = before the first '>', 1 = in header, 2 = in sequence
+        if (st == 0u) { if (b == '>') st = 1u; return false; }
+        if (b == '>') { st = 1u; out = '\n'; return true; }                // a record ends wherever the next '>' is
+        if (st == 1u) { if (b == '\n') st = 2u; return false; }
+        if (b == '\n' || b == '\r') return false;
+        out = b;
+        return true;
+    }
+}
+template <int KIND>
+__device__ __host__ __forceinline__ bool norm_final_newline(uint32_t st) {
+    if (KIND == NORM_FASTQ) return (st & 3u) == 1u && (st & 4u);           // last sequence line without '\n'
+    if (KIND == NORM_FASTA13) return (st & 4u) != 0;                       // :229-234
+    return st != 0u;                                                       // the last record ends at EOF
+}
+template <int KIND>
+__device__ __host__ __forceinline__ uint32_t norm_initial() { return KIND == NORM_FASTA13 ? 1u : 0u; }
+
+struct ChunkSummary {
+    uint32_t func;          // end state for start state s in bits [3s, 3s+3)
+    uint16_t count[8];      // bytes emitted for start state s
+};
+
+__device__ __forceinline__ uint32_t load_byte(const uint8_t* p, uint32_t i) { return p[i]; }
+
+template <int KIND>
+__global__ void __launch_bounds__(NTB) k_norm_summarise(const uint8_t* __restrict__ raw, uint64_t len, uint64_t nchunks, ChunkSummary* __restrict__ sum) {
+    const uint64_t c = (uint64_t)blockIdx.x * NTB + threadIdx.x;
+    if (c >= nchunks) return;
+    const uint64_t lo = c * NCH;
+    const uint32_t n = (uint32_t)(len - lo < NCH ? len - lo : NCH);
+    uint32_t st[8], cnt[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { st[s] = (uint32_t)s; cnt[s] = 0; }
+    const uint8_t* p = raw + lo;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t b = p[i];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            uint32_t o;
+            cnt[s] += norm_step<KIND>(st[s], b, o) ? 1u : 0u;
+        }
+    }
+    ChunkSummary r;
+    r.func = 0;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { r.func |= (st[s] & 7u) << (3 * s); r.count[s] = (uint16_t)cnt[s]; }
+    sum[c] = r;
+}
+
+struct ComposeOp {   // (a then b)(s) = b(a(s))
+    __device__ __host__ uint32_t operator()(uint32_t a, uint32_t b) const {
+        uint32_t r = 0;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) r |= ((b >> (3 * ((a >> (3 * s)) & 7u))) & 7u) << (3 * s);
+        return r;
+    }
+};
+static constexpr uint32_t kIdentityFunc = 0u | (1u << 3) | (2u << 6) | (3u << 9) | (4u << 12) | (5u << 15) | (6u << 18) | (7u << 21);
+
+__global__ void __launch_bounds__(NTB) k_norm_funcs(const ChunkSummary* __restrict__ sum, uint64_t nchunks, uint32_t* __restrict__ funcs) {
+    const uint64_t c = (uint64_t)blockIdx.x * NTB + threadIdx.x;
+    if (c < nchunks) funcs[c] = sum[c].func;
+}
+__global__ void __launch_bounds__(NTB) k_norm_pick(const ChunkSummary* __restrict__ sum, const uint32_t* __restrict__ prefix, uint64_t nchunks, uint32_t init,
+                                                  uint8_t* __restrict__ start_state, uint64_t* __restrict__ counts) {
+    const uint64_t c = (uint64_t)blockIdx.x * NTB + threadIdx.x;
+    if (c >= nchunks) return;
+    const uint32_t s = (prefix[c] >> (3 * init)) & 7u;
+    start_state[c] = (uint8_t)s;
+    counts[c] = sum[c].count[s];
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(NTB) k_norm_emit(const uint8_t* __restrict__ raw, uint64_t len, uint64_t nchunks, const uint8_t* __restrict__ start_state,
+                                                  const uint64_t* __restrict__ offs, uint8_t* __restrict__ out, uint64_t* __restrict__ out_len) {
+    const uint64_t c = (uint64_t)blockIdx.x * NTB + threadIdx.x;
+    if (c >= nchunks) return;
+    const uint64_t lo = c * NCH;
+    const uint32_t n = (uint32_t)(len - lo < NCH ? len - lo : NCH);
+    uint32_t st = start_state[c];
+    uint64_t w = offs[c];
+    const uint8_t* p = raw + lo;
+    uint32_t acc = 0, have = 0;                      // bytes packed towards the next aligned dword of `out`
+    for (uint32_t i = 0; i < n; ++i) {
+        uint32_t o;
+        if (norm_step<KIND>(st, p[i], o)) {
+            if (have == 0 && ((uintptr_t)(out + w) & 3)) { out[w++] = (uint8_t)o; continue; }   // head up to alignment
+            acc |= o << (8 * have);
+            if (++have == 4) { *(uint32_t*)(out + w) = acc; w += 4; acc = 0; have = 0; }
+        }
+    }
+    for (uint32_t k = 0; k < have; ++k) out[w++] = (uint8_t)(acc >> (8 * k));
+    if (c == nchunks - 1) {
+        if (norm_final_newline<KIND>(st)) out[w++] = '\n';
+        *out_len = w;
+    }
+}
+
+template <int KIND>
+static hipError_t normalise_impl(const uint8_t* d_raw, uint64_t len, uint8_t* d_out, uint64_t* d_out_len, hipStream_t s) {
+    const uint64_t nchunks = (len + NCH - 1) / NCH;
+    ChunkSummary* sum = nullptr;
+    uint32_t *funcs = nullptr, *prefix = nullptr;
+    uint8_t* start = nullptr;
+    uint64_t *counts = nullptr, *offs = nullptr;
+    void* tmp = nullptr;
+    const unsigned grid = (unsigned)((nchunks + NTB - 1) / NTB);
+    hipError_t e = hipMalloc((void**)&sum, sizeof(ChunkSummary) * nchunks);
+    if (e == hipSuccess) e = hipMalloc((void**)&funcs, 4 * nchunks);
+    if (e == hipSuccess) e = hipMalloc((void**)&prefix, 4 * nchunks);
+    if (e == hipSuccess) e = hipMalloc((void**)&start, nchunks);
+    if (e == hipSuccess) e = hipMalloc((void**)&counts, 8 * nchunks);
+    if (e == hipSuccess) e = hipMalloc((void**)&offs, 8 * nchunks);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_norm_summarise<KIND>, dim3(grid), dim3(NTB), 0, s, d_raw, len, nchunks, sum);
+        hipLaunchKernelGGL(k_norm_funcs, dim3(grid), dim3(NTB), 0, s, sum, nchunks, funcs);
+        e = hipGetLastError();
+    }
+    size_t tb = 0, tb2 = 0;
+    if (e == hipSuccess) e = rocprim::exclusive_scan(nullptr, tb, funcs, prefix, kIdentityFunc, (size_t)nchunks, ComposeOp(), s);
+    if (e == hipSuccess) e = rocprim::exclusive_scan(nullptr, tb2, counts, offs, (uint64_t)0, (size_t)nchunks, rocprim::plus<uint64_t>(), s);
+    if (tb2 > tb) tb = tb2;
+    if (e == hipSuccess) e = hipMalloc(&tmp, tb ? tb : 1);
+    if (e == hipSuccess) e = rocprim::exclusive_scan(tmp, tb, funcs, prefix, kIdentityFunc, (size_t)nchunks, ComposeOp(), s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_norm_pick, dim3(grid), dim3(NTB), 0, s, sum, prefix, nchunks, norm_initial<KIND>(), start, counts);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = rocprim::exclusive_scan(tmp, tb, counts, offs, (uint64_t)0, (size_t)nchunks, rocprim::plus<uint64_t>(), s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_norm_emit<KIND>, dim3(grid), dim3(NTB), 0, s, d_raw, len, nchunks, start, offs, d_out, d_out_len);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (tmp) (void)hipFree(tmp);
+    if (sum) (void)hipFree(sum);
+    if (funcs) (void)hipFree(funcs);
+    if (prefix) (void)hipFree(prefix);
+    if (start) (void)hipFree(start);
+    if (counts) (void)hipFree(counts);
+    if (offs) (void)hipFree(offs);
+    return e;
+}
+
+// d_out needs len + 1 bytes. *out_len (host) receives the normalised length. format: AIX_FMT_FASTA / AIX_FMT_FASTQ.
+hipError_t normalise_device(const uint8_t* d_raw, uint64_t len, int format, int fasta_mode, uint8_t* d_out, uint64_t* out_len, hipStream_t s) {
+    *out_len = 0;
+    if (len == 0) return hipSuccess;
+    uint64_t* d_len = nullptr;
+    hipError_t e = hipMalloc((void**)&d_len, 8);
+    if (e != hipSuccess) return e;
+    if (format == AIX_FMT_FASTQ) e = normalise_impl<NORM_FASTQ>(d_raw, len, d_out, d_len, s);
+    else if (fasta_mode == 0) e = normalise_impl<NORM_FASTA13>(d_raw, len, d_out, d_len, s);
+    else e = normalise_impl<NORM_FASTAK1>(d_raw, len, d_out, d_len, s);
+    if (e == hipSuccess) e = hipMemcpy(out_len, d_len, 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d_len);
+    return e;
+}
+
+}  // namespace aix

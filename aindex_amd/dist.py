@@ -75,3 +75,39 @@ def all_reduce_max_float(x: float, device=None) -> float:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
     return x
+
+
+# ---- sharded counting: every rank counts a contiguous, record-aligned share, one all-reduce --------
+def count13_sharded(index, plain: bytes, device=None):
+    """13-mer counts of a PLAIN reads buffer split over the ranks of the default process group.
+    Returns a torch.int64 tensor [4^13] (mphf order, u64 bit patterns) holding the global counts on every rank."""
+    import torch
+    rank, world, local = rank_world()
+    dev = index.device if device is None else device
+    mine = shard_lines(plain, rank, world)
+    t = torch.frombuffer(bytearray(mine) if mine else bytearray(1), dtype=torch.uint8)[: len(mine)].to(f"cuda:{dev}")
+    out = index.count13_t(t)
+    return all_reduce_sum_(out)
+
+
+def count23_sharded(index, plain: bytes, canon_mode: int = 2, device=None):
+    """tf[] histogram of a PLAIN reads buffer against the index's fixed key set, split over the ranks.
+    Returns a torch.int32 tensor [n] (u32 bit patterns) holding the global histogram on every rank."""
+    import torch
+    rank, world, local = rank_world()
+    dev = index.device if device is None else device
+    mine = shard_lines(plain, rank, world)
+    t = torch.frombuffer(bytearray(mine) if mine else bytearray(1), dtype=torch.uint8)[: len(mine)].to(f"cuda:{dev}")
+    out = torch.zeros(index.n, dtype=torch.int32, device=f"cuda:{dev}")
+    index.count23_fixed_t(t, canon_mode, out)
+    return all_reduce_sum_(out)
+
+
+def lookup_sharded(index, kmers_u8, device=None):
+    """Batch tf lookup with the queries split into contiguous ranges over the ranks (index replicated); every rank
+    returns only ITS range [lo, hi) as (lo, hi, uint32 numpy array) — no collective on the data path."""
+    import numpy as np
+    rank, world, _ = rank_world()
+    a = np.ascontiguousarray(kmers_u8, dtype=np.uint8).reshape(-1, index.k)
+    lo, hi = shard_range(a.shape[0], rank, world)
+    return lo, hi, index.tf_ascii(a[lo:hi])

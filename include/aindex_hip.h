@@ -200,6 +200,10 @@ int aix_count_distinct(const char* buf, uint64_t len, int format, int k, int can
  * fasta_mode: 0 = count_kmers13 rules, 1 = kmer_counter rules ('>' anywhere starts a record). */
 int aix_normalize_reads(const char* buf, uint64_t len, int format, int fasta_mode, char* out, uint64_t* out_len);
 int aix_detect_format(const char* buf, uint64_t len);  /* count_kmers13.cpp:194-206 */
+/* The same normalisation for a buffer already in HBM (byte-identical output; the readers are finite-state transducers,
+ * resolved with a parallel scan of per-chunk transition functions). format must be PLAIN, FASTA or FASTQ; d_out holds
+ * len+1 bytes; *out_len is a HOST pointer; the call synchronises the stream. */
+int aix_normalize_reads_dev(const char* d_raw, uint64_t len, int format, int fasta_mode, char* d_out, uint64_t* out_len, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Synthetic inputs generated directly in HBM (mirrored by aindex_amd/synth.py).
