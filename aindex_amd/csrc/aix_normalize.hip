@@ -2,10 +2,10 @@
 //
 // Same bytes as the host routine aix_normalize_reads (readers of count_kmers13.cpp:211-272 and
 // count_kmers.cpp:250-295). Each reader is a finite-state transducer over bytes with <= 8 states that emits at
-// most one byte per input byte (plus one '\n' at end of input), so the state at the start of every 256-byte chunk
+// most one byte per input byte (plus one '\n' at end of input), so the state at the start of every 128-byte chunk
 // comes from an exclusive scan of per-chunk transition FUNCTIONS (3 bits x 8 states packed in a u32, composed
 // associatively), and the output offset of every chunk from a second (sum) scan:
-//   k_norm_summarise : every chunk, simulated from all 8 start states at once -> transition function + emit counts
+//   k_norm_summarise : every chunk, simulated from every reachable start state at once -> transition function + emit counts
 //   rocPRIM scan #1  : function composition  -> true start state per chunk
 //   k_norm_pick      : emit count under the true start state
 //   rocPRIM scan #2  : output offsets
@@ -19,10 +19,11 @@
 
 namespace aix {
 
-static constexpr int NCH = 256;     // bytes per chunk
+static constexpr int NCH = 128;     // bytes per chunk (one lane)
 static constexpr int NTB = 256;
 
 enum NormKind { NORM_FASTQ = 0, NORM_FASTA13 = 1, NORM_FASTAK1 = 2 };
+static constexpr uint32_t kIdentityFuncConst = 0u | (1u << 3) | (2u << 6) | (3u << 9) | (4u << 12) | (5u << 15) | (6u << 18) | (7u << 21);
 
 // One transducer step. Returns true when a byte is emitted (in `out`). States are 0..7.
 template <int KIND>
@@ -78,10 +79,34 @@ __device__ __host__ __forceinline__ uint32_t norm_initial() { return KIND == NOR
 
 struct ChunkSummary {
     uint32_t func;          // end state for start state s in bits [3s, 3s+3)
-    uint16_t count[8];      // bytes emitted for start state s
+    uint8_t count[8];       // bytes emitted for start state s (<= NCH = 128)
 };
 
-__device__ __forceinline__ uint32_t load_byte(const uint8_t* p, uint32_t i) { return p[i]; }
+// the start states that can actually occur, per reader (the others keep the identity mapping / zero counts)
+template <int KIND> struct NormStates;
+template <> struct NormStates<NORM_FASTQ>   { static constexpr int N = 5; __device__ static constexpr uint32_t at(int i) { return i == 0 ? 0u : i == 1 ? 1u : i == 2 ? 5u : i == 3 ? 2u : 3u; } };
+template <> struct NormStates<NORM_FASTA13> { static constexpr int N = 4; __device__ static constexpr uint32_t at(int i) { return i == 0 ? 1u : i == 1 ? 2u : i == 2 ? 4u : 5u; } };
+template <> struct NormStates<NORM_FASTAK1> { static constexpr int N = 3; __device__ static constexpr uint32_t at(int i) { return (uint32_t)i; } };
+
+// a chunk's bytes in registers: full, 16-byte aligned chunks come in as 8 x uint4; anything else byte by byte
+struct ChunkBytes {
+    uint32_t w[NCH / 4];
+    __device__ __forceinline__ uint32_t byte(int i) const { return (w[i >> 2] >> (8 * (i & 3))) & 0xFFu; }
+};
+__device__ __forceinline__ void load_chunk(const uint8_t* __restrict__ p, uint32_t n, ChunkBytes& cb) {
+    if (n == NCH && (((uintptr_t)p) & 15) == 0) {
+        const uint4* q = (const uint4*)p;
+#pragma unroll
+        for (int k = 0; k < NCH / 16; ++k) {
+            const uint4 v = q[k];
+            cb.w[4 * k] = v.x; cb.w[4 * k + 1] = v.y; cb.w[4 * k + 2] = v.z; cb.w[4 * k + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NCH / 4; ++k) cb.w[k] = 0;
+        for (uint32_t i = 0; i < n; ++i) cb.w[i >> 2] |= (uint32_t)p[i] << (8 * (i & 3));
+    }
+}
 
 template <int KIND>
 __global__ void __launch_bounds__(NTB) k_norm_summarise(const uint8_t* __restrict__ raw, uint64_t len, uint64_t nchunks, ChunkSummary* __restrict__ sum) {
@@ -89,22 +114,33 @@ __global__ void __launch_bounds__(NTB) k_norm_summarise(const uint8_t* __restric
     if (c >= nchunks) return;
     const uint64_t lo = c * NCH;
     const uint32_t n = (uint32_t)(len - lo < NCH ? len - lo : NCH);
-    uint32_t st[8], cnt[8];
+    constexpr int NS = NormStates<KIND>::N;
+    uint32_t st[NS], cnt[NS];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) { st[s] = (uint32_t)s; cnt[s] = 0; }
-    const uint8_t* p = raw + lo;
-    for (uint32_t i = 0; i < n; ++i) {
-        const uint32_t b = p[i];
+    for (int s = 0; s < NS; ++s) { st[s] = NormStates<KIND>::at(s); cnt[s] = 0; }
+    ChunkBytes cb;
+    load_chunk(raw + lo, n, cb);
+#pragma unroll 16
+    for (int i = 0; i < NCH; ++i) {
+        if ((uint32_t)i < n) {
+            const uint32_t b = cb.byte(i);
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            uint32_t o;
-            cnt[s] += norm_step<KIND>(st[s], b, o) ? 1u : 0u;
+            for (int s = 0; s < NS; ++s) {
+                uint32_t o;
+                cnt[s] += norm_step<KIND>(st[s], b, o) ? 1u : 0u;
+            }
         }
     }
     ChunkSummary r;
-    r.func = 0;
+    r.func = kIdentityFuncConst;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) { r.func |= (st[s] & 7u) << (3 * s); r.count[s] = (uint16_t)cnt[s]; }
+    for (int s = 0; s < 8; ++s) r.count[s] = 0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const uint32_t from = NormStates<KIND>::at(s);
+        r.func = (r.func & ~(7u << (3 * from))) | ((st[s] & 7u) << (3 * from));
+        r.count[from] = (uint8_t)cnt[s];
+    }
     sum[c] = r;
 }
 
@@ -140,11 +176,13 @@ __global__ void __launch_bounds__(NTB) k_norm_emit(const uint8_t* __restrict__ r
     const uint32_t n = (uint32_t)(len - lo < NCH ? len - lo : NCH);
     uint32_t st = start_state[c];
     uint64_t w = offs[c];
-    const uint8_t* p = raw + lo;
+    ChunkBytes cb;
+    load_chunk(raw + lo, n, cb);
     uint32_t acc = 0, have = 0;                      // bytes packed towards the next aligned dword of `out`
-    for (uint32_t i = 0; i < n; ++i) {
+#pragma unroll 16
+    for (int i = 0; i < NCH; ++i) {
         uint32_t o;
-        if (norm_step<KIND>(st, p[i], o)) {
+        if ((uint32_t)i < n && norm_step<KIND>(st, cb.byte(i), o)) {
             if (have == 0 && ((uintptr_t)(out + w) & 3)) { out[w++] = (uint8_t)o; continue; }   // head up to alignment
             acc |= o << (8 * have);
             if (++have == 4) { *(uint32_t*)(out + w) = acc; w += 4; acc = 0; have = 0; }

@@ -160,7 +160,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="lookup23", choices=["lookup23", "lookup13", "count13", "count23", "gather", "coverage23"])
+    ap.add_argument("--workload", default="lookup23", choices=["lookup23", "lookup13", "count13", "count23", "gather", "coverage23", "positions23", "normalize"])
     ap.add_argument("--seqs", type=int, default=100_000)
     ap.add_argument("--seq-len", type=int, default=10_000)
     ap.add_argument("--table-mib", type=int, default=4096)
@@ -307,6 +307,46 @@ def main():
                                "sequences_per_step_per_gpu": a.seqs, "positions_per_step": positions, "nonzero_fraction": float((outp != 0).float().mean().item())},
                     "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                  "traffic": None, "kernel": "k_coverage", "kernel_ms": kern_ms, "positions_per_sec": positions / (kern_ms * 1e-3)}})
+
+    elif a.workload == "positions23":
+        from aindex_amd._lib import lib, check, vp
+        ix, g, keys, counts, pf = build_index23(a.genome, rank, world, dev, cache)
+        reads_t = engine.synth_reads_t(41, g, a.reads, 150, rc_half=True, n_rate_ppm=1000)
+        reads = reads_t.cpu().numpy()
+        t0 = time.perf_counter()
+        indices, pos = ix.positions_fill(reads.tobytes())
+        dt = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        indices, pos = ix.positions_fill(reads.tobytes())
+        dt = min(dt, time.perf_counter() - t0)
+        out.update({"metric": "reads_per_sec_positions_fill_23mer", "value": a.reads / dt, "unit": "reads/s", "ms_per_step": dt * 1e3, "dtype": "u64",
+                    "steps": 2, "warmup": 0,
+                    "config": {"workload": "A1+A2: positions index of 150 bp reads against the fixed 23-mer index, host buffers in and out (PCIe inclusive)",
+                               "reads": a.reads, "windows": int(reads.shape[0] - 22), "positions_total": int(indices[-1]), "filled": int((pos != 0).sum())},
+                    "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                                 "kernel": "k_a2_probe + rocprim radix_sort_pairs + k_a2_first/k_a2_place", "kernel_ms": dt * 1e3}})
+
+    elif a.workload == "normalize":
+        from aindex_amd import counting
+        g = engine.synth_genome_t(23, 4_000_000, dev)
+        reads = engine.synth_reads_t(41, g, a.reads, 150, n_rate_ppm=1000).cpu().numpy().reshape(-1, 151)
+        fq = np.empty((a.reads, 4 + 151 + 2 + 151), dtype=np.uint8)          # "@r0\n" + seq\n + "+\n" + qual\n
+        fq[:, :4] = np.frombuffer(b"@r0\n", dtype=np.uint8)
+        fq[:, 4:155] = reads
+        fq[:, 155:157] = np.frombuffer(b"+\n", dtype=np.uint8)
+        fq[:, 157:307] = ord("I")
+        fq[:, 307] = ord("\n")
+        raw = torch.from_numpy(fq.reshape(-1)).to(f"cuda:{dev}")
+        res = {}
+        step = lambda: res.__setitem__("o", counting.normalize_t(raw, _lib.FMT_FASTQ, 0))
+        wall, kern_ms, _ = timed_steps(step, a.steps, a.warmup, dev)
+        assert res["o"].numel() == a.reads * 151
+        nbytes = raw.numel()
+        out.update({"metric": "bytes_per_sec_fastq_normalise", "value": nbytes * a.steps / wall, "unit": "B/s", "ms_per_step": wall / a.steps * 1e3, "dtype": "u8",
+                    "config": {"workload": "FASTQ -> PLAIN normalisation on the device", "reads": a.reads, "raw_bytes": nbytes},
+                    "roofline": {"bound": "hbm", "achieved": (2 * nbytes + a.reads * 151) / (kern_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": (2 * nbytes + a.reads * 151) / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                 "kernel": "k_norm_summarise + 2 rocprim scans + k_norm_emit", "kernel_ms": kern_ms}})
 
     elif a.workload == "gather":
         from aindex_amd._lib import lib, check, vp
