@@ -534,7 +534,7 @@ extern "C" int aix_count13_dev(aix_index_t* h, const char* d_plain, uint64_t len
     DevGuard g(h->device);
     std::lock_guard<std::mutex> lk(h->count_mutex);
     hipStream_t s = (hipStream_t)stream;
-    static const bool use_atomics = getenv("AIX_COUNT13_ATOMICS") != nullptr;      // A/B switch for measurements
+    const bool use_atomics = getenv("AIX_COUNT13_ATOMICS") != nullptr;             // A/B switch for measurements / tests
     if (use_atomics || len >= (1ull << 32)) {
         if (!h->scratch13) {
             HIPCHK(hipMalloc((void**)&h->scratch13, 8 * AIX_TOTAL_13MERS));

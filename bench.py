@@ -171,6 +171,8 @@ def main():
     ap.add_argument("--reads", type=int, default=10_000_000)
     ap.add_argument("--cpu-sample", type=int, default=20_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary counting measurement of the default workload")
+    ap.add_argument("--reads23", type=int, default=2_000_000)
     ap.add_argument("--no-fastpath", action="store_true", help="force the reference's two-probe order")
     ap.add_argument("--no-fingerprint", action="store_true", help="disable the 4-bit fingerprint filter")
     a = ap.parse_args()
@@ -221,6 +223,26 @@ def main():
         if tr:
             out["roofline"]["traffic"] = tr.get("bytes_per_launch")
             out["roofline"]["traffic_source"] = tr.get("source")
+        if not a.no_secondary:
+            # the other half of BASELINE.json's metric: reads/s counted, each rank its own reads, tf[] merged by one
+            # all-reduce (RCCL over xGMI at N > 1). Never allowed to take the headline number down with it.
+            sec = {}
+            try:
+                reads = engine.synth_reads_t(41, g, a.reads23, 150, rc_half=True, n_rate_ppm=1000, first_read=rank * a.reads23)
+                tfh = torch.zeros(ix.n, dtype=torch.int32, device=f"cuda:{dev}")
+                def step23():
+                    tfh.zero_()
+                    ix.count23_fixed_t(reads, _lib.CANON_TRUE_RC, tfh)
+                    adist.all_reduce_sum_(tfh)
+                w23, k23, _ = timed_steps(step23, 3, 1, dev)
+                total = int(tfh.to(torch.int64).sum().item())
+                sec["count23_fixed_mphf"] = {"metric": "reads_per_sec_23mer_count_fixed_mphf", "value": world * a.reads23 * 3 / w23, "unit": "reads/s",
+                                             "reads_per_step_per_gpu": a.reads23, "ms_per_step": w23 / 3 * 1e3, "windows_counted_all_ranks": total,
+                                             "collective": "all_reduce(sum) of int32 tf[n]" if world > 1 else "none (1 rank)"}
+                del reads, tfh
+            except Exception as e:  # pragma: no cover
+                sec["count23_fixed_mphf"] = {"error": f"{type(e).__name__}: {e}"}
+            out["secondary"] = sec
         if rank == 0 and world == 1 and not a.no_cpu_baseline:
             s = min(a.cpu_sample, a.queries)
             qs = q[: s * 23].cpu().numpy()

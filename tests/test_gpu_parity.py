@@ -582,3 +582,52 @@ def test_device_normalisation_equals_host(gold):
         t = torch.frombuffer(bytearray(buf) if buf else bytearray(1), dtype=torch.uint8)[: len(buf)].cuda()
         got = counting.normalize_t(t, fmt, mode).cpu().numpy().tobytes()
         assert got == want, (buf[:60], fmt, mode, len(got), len(want))
+
+
+# ------------------------------------------------------------------------------------------------
+# full-size style checks (BASELINE config sizes scaled to seconds): oracle on all host cores + invariants
+# ------------------------------------------------------------------------------------------------
+def test_count13_million_reads_vs_oracle_and_atomics_path(ix13):
+    import torch
+    from aindex_amd import engine
+    from pf13 import pf13_path
+    g = engine.synth_genome_t(13, 4_000_000)
+    reads = engine.synth_reads_t(14, g, 1_000_000, 150, n_rate_ppm=1000)
+    got = ix13.count13_t(reads).cpu().numpy().view(np.uint64)
+    os.environ["AIX_COUNT13_ATOMICS"] = "1"
+    try:
+        got_atomic = ix13.count13_t(reads).cpu().numpy().view(np.uint64)
+    finally:
+        del os.environ["AIX_COUNT13_ATOMICS"]
+    assert np.array_equal(got, got_atomic)                       # partition + LDS histogram == scattered atomics
+    host = reads.cpu().numpy().tobytes()
+    want = O.count13(O.OracleMphf(pf13_path()), host, 0, threads=min(os.cpu_count() or 8, 64))
+    assert np.array_equal(got, want)
+    # invariant: total = number of 13-windows free of N in every read
+    r = np.frombuffer(host, dtype=np.uint8).reshape(-1, 151)[:, :150]
+    isn = (r == ord("N")).astype(np.int32)
+    c = np.cumsum(np.concatenate([np.zeros((r.shape[0], 1), np.int32), isn], axis=1), axis=1)
+    valid = int(((c[:, 13:] - c[:, :-13]) == 0).sum())
+    assert int(got.sum()) == valid
+
+
+def test_count23_sum_equals_valid_windows_at_scale(canon_case):
+    import torch
+    from aindex_amd import engine, counting
+    ix = canon_case["ix"]
+    g = engine.synth_genome_t(23, 300_000)                     # the genome the index was built from
+    reads = engine.synth_reads_t(41, g, 500_000, 150, rc_half=True, n_rate_ppm=1000)
+    tf = ix.count23_fixed_t(reads, _lib.CANON_TRUE_RC)
+    codes = counting.window_codes_t(reads, 23, _lib.CANON_TRUE_RC)
+    valid = int((codes != -1).sum().item())
+    assert int(tf.to(torch.int64).sum().item()) == valid        # every N-free window of a genome read is a key
+    # and the per-key histogram equals the sort/run-length result scattered through the MPHF
+    keys, counts = counting.count_distinct_t(reads, 23, _lib.CANON_TRUE_RC)
+    exp = np.zeros(ix.n, dtype=np.int64)
+    slot = np.searchsorted(canon_case["keys"], keys.cpu().numpy().view(np.uint64))
+    assert np.array_equal(canon_case["keys"][slot], keys.cpu().numpy().view(np.uint64))
+    # slot in sorted-key order -> MPHF slot via kid lookup of the keys
+    kid, strand = ix.kid_strand_ascii(synth.decode_kmers(keys.cpu().numpy().view(np.uint64), 23))
+    assert (strand == 1).all()
+    exp[kid.astype(np.int64)] = counts.cpu().numpy()
+    assert np.array_equal(tf.cpu().numpy().astype(np.int64), exp)
