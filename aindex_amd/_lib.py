@@ -83,6 +83,7 @@ SIGNATURES = {
     "aix_detect_format": (i32, [vp, u64]),
     "aix_synth_genome_dev": (i32, [u64, u64, vp, vp]),
     "aix_synth_kmers_dev": (i32, [u64, u64, u64, i32, vp, vp]),
+    "aix_synth_mix23_dev": (i32, [u64, vp, u64, u64, u64, vp, vp]),
     "aix_synth_reads_dev": (i32, [u64, vp, u64, u64, u64, u32, i32, u32, vp, vp]),
     "aix_bench_gather_dev": (i32, [vp, u64, i32, i32, u64, u64, vp, vp]),
     "aix_pf_build": (i32, [vp, u64, u32, C.POINTER(vp), C.POINTER(u64)]),

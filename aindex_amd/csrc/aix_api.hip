@@ -595,6 +595,11 @@ extern "C" int aix_synth_kmers_dev(uint64_t seed, uint64_t first, uint64_t N, in
     HIPCHK(launch_synth_kmers(seed, first, N, k, (uint8_t*)d_out, (hipStream_t)stream));
     return AIX_OK;
 }
+extern "C" int aix_synth_mix23_dev(uint64_t seed, const char* d_genome, uint64_t genome_len, uint64_t first, uint64_t N, char* d_out, void* stream) {
+    if (!d_genome || (N && !d_out) || genome_len < 23) return AIX_ERR_ARG;
+    HIPCHK(launch_synth_mix23(seed, (const uint8_t*)d_genome, genome_len, first, N, (uint8_t*)d_out, (hipStream_t)stream));
+    return AIX_OK;
+}
 extern "C" int aix_synth_reads_dev(uint64_t seed, const char* d_genome, uint64_t genome_len, uint64_t first_read, uint64_t n_reads, uint32_t read_len,
                                    int rc_half, uint32_t n_rate_ppm, char* d_out, void* stream) {
     if (!d_genome || (n_reads && !d_out) || read_len == 0 || genome_len < read_len) return AIX_ERR_ARG;

@@ -75,6 +75,7 @@ hipError_t normalise_device(const uint8_t* d_raw, uint64_t len, int format, int 
 // synthetic generators
 hipError_t launch_synth_genome(uint64_t seed, uint64_t length, uint8_t* out, hipStream_t s);
 hipError_t launch_synth_kmers(uint64_t seed, uint64_t first, uint64_t N, int k, uint8_t* out, hipStream_t s);
+hipError_t launch_synth_mix23(uint64_t seed, const uint8_t* genome, uint64_t glen, uint64_t first, uint64_t N, uint8_t* out, hipStream_t s);
 hipError_t launch_synth_reads(uint64_t seed, const uint8_t* genome, uint64_t genome_len, uint64_t first_read, uint64_t n_reads,
                               uint32_t read_len, int rc_half, uint32_t n_rate_ppm, uint8_t* out, hipStream_t s);
 

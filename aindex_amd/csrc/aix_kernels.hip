@@ -568,6 +568,32 @@ __global__ void __launch_bounds__(kBlock) k_synth_reads(uint64_t seed, const uin
     }
 }
 
+// Q_mix of SURVEY §8d: query i is, with probability 1/2, a 23-mer window of the genome at a uniform position on a
+// uniform strand, else a uniform-random 23-mer.
+__global__ void __launch_bounds__(kBlock) k_synth_mix23(uint64_t seed, const uint8_t* __restrict__ genome, uint64_t glen, uint64_t first, uint64_t N,
+                                                       uint8_t* __restrict__ out) {
+    const uint64_t total = N * 23, stride = (uint64_t)gridDim.x * kBlock;
+    const uint64_t span = glen - 22;
+    for (uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += stride) {
+        const uint64_t i = t / 23, j = t - i * 23;
+        const uint64_t v = sm64(seed, first + i);
+        uint8_t ch;
+        if (v & 1) {
+            const uint64_t r = sm64(seed ^ 0xA5A5A5A5ULL, first + i);
+            ch = (uint8_t)(AIX_LUT_ACGT >> (8 * ((r >> (2 * (22 - (int)j))) & 3)));
+        } else {
+            const uint64_t pos = ((v >> 32) * span) >> 32;
+            if (v & 2) {
+                const uint8_t g = genome[pos + 22 - j];
+                ch = g == 'A' ? 'T' : g == 'C' ? 'G' : g == 'G' ? 'C' : g == 'T' ? 'A' : g;
+            } else {
+                ch = genome[pos + j];
+            }
+        }
+        out[t] = ch;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // random-gather roofline probe: uniform-random ELEM-byte reads over a large table,
 // UNROLL independent reads in flight per lane. The denominator the lookup kernels are judged against.
@@ -701,6 +727,10 @@ hipError_t launch_synth_genome(uint64_t seed, uint64_t length, uint8_t* out, hip
 hipError_t launch_synth_kmers(uint64_t seed, uint64_t first, uint64_t N, int k, uint8_t* out, hipStream_t s) {
     if (N == 0) return hipSuccess;
     AIX_LAUNCH(k_synth_kmers, N * (uint64_t)k, s, seed, first, N, k, out);
+}
+hipError_t launch_synth_mix23(uint64_t seed, const uint8_t* genome, uint64_t glen, uint64_t first, uint64_t N, uint8_t* out, hipStream_t s) {
+    if (N == 0) return hipSuccess;
+    AIX_LAUNCH(k_synth_mix23, N * 23, s, seed, genome, glen, first, N, out);
 }
 hipError_t launch_synth_reads(uint64_t seed, const uint8_t* genome, uint64_t glen, uint64_t first_read, uint64_t n_reads, uint32_t read_len, int rc_half,
                               uint32_t n_ppm, uint8_t* out, hipStream_t s) {

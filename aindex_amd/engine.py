@@ -340,3 +340,13 @@ def synth_reads_t(seed: int, genome_t, n_reads: int, read_len: int, rc_half: boo
         check(lib().aix_synth_reads_dev(seed, vp(genome_t.data_ptr()), genome_t.numel(), first_read, n_reads, read_len,
                                         int(rc_half), n_rate_ppm, vp(t.data_ptr()), _stream_ptr()), "aix_synth_reads_dev")
     return t
+
+
+def synth_mix23_t(seed: int, genome_t, n: int, first: int = 0):
+    """Q_mix: 50 % genome windows on a random strand, 50 % uniform-random 23-mers, generated in HBM."""
+    import torch
+    t = torch.empty(n * 23 + 16, dtype=torch.uint8, device=genome_t.device)[: n * 23]
+    with torch.cuda.device(genome_t.device):
+        check(lib().aix_synth_mix23_dev(seed, vp(genome_t.data_ptr()), genome_t.numel(), first, n, vp(t.data_ptr()), _stream_ptr()),
+              "aix_synth_mix23_dev")
+    return t

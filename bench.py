@@ -175,6 +175,7 @@ def main():
     ap.add_argument("--reads23", type=int, default=2_000_000)
     ap.add_argument("--no-fastpath", action="store_true", help="force the reference's two-probe order")
     ap.add_argument("--no-fingerprint", action="store_true", help="disable the 4-bit fingerprint filter")
+    ap.add_argument("--query-mix", action="store_true", help="Q_mix: 50 %% genome windows on a random strand + 50 %% random (seed 8)")
     a = ap.parse_args()
 
     import torch
@@ -196,7 +197,10 @@ def main():
             ix.set_canonical_fastpath(False)
         if a.no_fingerprint:
             ix.set_fingerprint_filter(False)
-        q = engine.synth_kmers_t(7, a.queries, 23, dev, first=rank * a.queries)
+        if a.query_mix:
+            q = engine.synth_mix23_t(8, g, a.queries, first=rank * a.queries)
+        else:
+            q = engine.synth_kmers_t(7, a.queries, 23, dev, first=rank * a.queries)
         res = torch.empty(a.queries, dtype=torch.int32, device=f"cuda:{dev}")
         step = lambda: ix.tf_ascii_t(q, res)
         wall, kern_ms, _ = timed_steps(step, a.steps, a.warmup, dev)
@@ -213,7 +217,7 @@ def main():
                     "ms_per_step": wall / a.steps * 1e3, "dtype": "u64",
                     "config": {"workload": "configs[2]: 23-mer emphf MPHF batch lookup, uniform-random 23-mer ASCII queries resident in HBM",
                                "queries_per_step_per_gpu": a.queries, "index_keys": ix.n, "genome_bp": a.genome,
-                               "query_seed": 7, "hit_fraction": hits / a.queries, "probes_per_query": probes,
+                               "query_seed": 8 if a.query_mix else 7, "query_set": "Q_mix" if a.query_mix else "Q_rand", "hit_fraction": hits / a.queries, "probes_per_query": probes,
                                "canonical_fastpath": bool(ix.canonical_only and not a.no_fastpath),
                                "fingerprint_filter": not a.no_fingerprint, "checker_reads_per_query": checker_reads, "parallelism": f"replica x{world}"},
                     "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

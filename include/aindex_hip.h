@@ -210,6 +210,8 @@ int aix_normalize_reads_dev(const char* d_raw, uint64_t len, int format, int fas
  * ------------------------------------------------------------------------------------------ */
 int aix_synth_genome_dev(uint64_t seed, uint64_t length, char* d_out, void* stream);
 int aix_synth_kmers_dev(uint64_t seed, uint64_t first, uint64_t N, int k, char* d_out, void* stream);
+int aix_synth_mix23_dev(uint64_t seed, const char* d_genome, uint64_t genome_len, uint64_t first, uint64_t N,
+                        char* d_out /* N*23 */, void* stream);   /* Q_mix: 50 % genome windows on a random strand, 50 % random */
 int aix_synth_reads_dev(uint64_t seed, const char* d_genome, uint64_t genome_len, uint64_t first_read,
                         uint64_t n_reads, uint32_t read_len, int rc_half, uint32_t n_rate_ppm,
                         char* d_out /* n_reads*(read_len+1) */, void* stream);
