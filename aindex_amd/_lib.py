@@ -91,6 +91,7 @@ SIGNATURES = {
     "aix_pf_build_codes": (i32, [vp, u64, i32, C.POINTER(vp), C.POINTER(u64)]),
     "aix_index_scatter": (i32, [vp, u64, vp, vp, u64, i32, vp, vp]),
     "aix_index_build_23_codes_dev": (i32, [vp, u64, vp, vp, u64, i32, vp, C.POINTER(vp)]),
+    "aix_pf_build_codes_dev": (i32, [vp, u64, i32, i32, vp, C.POINTER(vp), C.POINTER(u64)]),
     "aix_pf_build_all_13mers": (i32, [C.POINTER(vp), C.POINTER(u64)]),
     "aix_free": (None, [vp]),
     "aix_selftest_mod": (u64, [u64, u64]),

@@ -48,6 +48,17 @@ def build_pf_codes(codes: np.ndarray, k: int) -> bytes:
     return _take(p, n)
 
 
+def build_pf_codes_t(keys_t, k: int) -> bytes:
+    """GPU construction (parallel peeling) for keys already in HBM (int64/uint64 tensor of 2-bit codes). The result is a
+    valid emphf `.pf` for the reference, not byte-identical to `build_pf_codes` (see aix_builder_gpu.hip)."""
+    import torch
+    p, n = vp(), C.c_uint64()
+    with torch.cuda.device(keys_t.device):
+        check(lib().aix_pf_build_codes_dev(vp(keys_t.data_ptr()), keys_t.numel(), k, keys_t.device.index,
+                                           vp(torch.cuda.current_stream().cuda_stream), C.byref(p), C.byref(n)), "aix_pf_build_codes_dev")
+    return _take(p, n)
+
+
 def build_all_13mers_pf(path: str | None = None) -> bytes:
     """The MPHF over all 4^13 13-mers in 2-bit order (generate_all_13mers + compute_mphf_seq)."""
     p, n = vp(), C.c_uint64()

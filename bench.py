@@ -29,7 +29,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def build_index23(genome_len, rank, world, device, cache_dir):
+def build_index23(genome_len, rank, world, device, cache_dir, gpu_builder=False):
     """Synthetic config-3 index, built without the oracle: keys/counts on the GPU, MPHF on the host CPU."""
     import torch
     from aindex_amd import builder, counting, engine, _lib
@@ -43,7 +43,9 @@ def build_index23(genome_len, rank, world, device, cache_dir):
     t1 = time.time()
     pf_path = os.path.join(cache_dir, f"g23_{genome_len}.pf")
     pf = None
-    if rank == 0:
+    if gpu_builder:
+        pf = builder.build_pf_codes_t(keys, 23)       # every rank builds its own (deterministic) copy in HBM
+    elif rank == 0:
         if os.path.exists(pf_path):
             pf = open(pf_path, "rb").read()
             if int(np.frombuffer(pf[:8], dtype=np.uint64)[0]) != n:
@@ -54,7 +56,7 @@ def build_index23(genome_len, rank, world, device, cache_dir):
             with open(pf_path + ".tmp", "wb") as f:
                 f.write(pf)
             os.replace(pf_path + ".tmp", pf_path)
-    if world > 1:
+    if world > 1 and not gpu_builder:
         import torch.distributed as dist
         sz = torch.tensor([len(pf) if rank == 0 else 0], dtype=torch.int64, device=f"cuda:{device}")
         dist.broadcast(sz, 0)
@@ -175,6 +177,7 @@ def main():
     ap.add_argument("--reads23", type=int, default=2_000_000)
     ap.add_argument("--no-fastpath", action="store_true", help="force the reference's two-probe order")
     ap.add_argument("--no-fingerprint", action="store_true", help="disable the 4-bit fingerprint filter")
+    ap.add_argument("--gpu-builder", action="store_true", help="build the MPHF on the GPU (parallel peeling) instead of the host")
     ap.add_argument("--query-mix", action="store_true", help="Q_mix: 50 %% genome windows on a random strand + 50 %% random (seed 8)")
     a = ap.parse_args()
 
@@ -192,7 +195,7 @@ def main():
            "vs_baseline": None, "data": "synthetic"}
 
     if a.workload == "lookup23":
-        ix, g, keys, counts, pf = build_index23(a.genome, rank, world, dev, cache)
+        ix, g, keys, counts, pf = build_index23(a.genome, rank, world, dev, cache, a.gpu_builder)
         if a.no_fastpath:
             ix.set_canonical_fastpath(False)
         if a.no_fingerprint:

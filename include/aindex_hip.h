@@ -227,6 +227,10 @@ int aix_pf_build(const char* keys /* n*key_len bytes */, uint64_t n, uint32_t ke
 int aix_pf_build_ragged(const char* bytes, const uint64_t* offsets /* n+1 */, uint64_t n, void** pf_out, uint64_t* pf_len);
 int aix_pf_build_codes(const uint64_t* codes, uint64_t n, int k, void** pf_out, uint64_t* pf_len); /* keys = ASCII of 2-bit codes */
 int aix_pf_build_all_13mers(void** pf_out, uint64_t* pf_len);   /* generate_all_13mers + build_13mer_hash */
+/* The same construction on the GPU for keys (2-bit codes, ASCII-hashed) already in HBM: same seed stream, hash domain
+ * and hypergraph, parallel peeling — a valid emphf .pf that the reference loads and evaluates, but NOT byte-identical
+ * to compute_mphf_seq's (the bit-pair values depend on the peeling order). n and 3*hash_domain must be < 2^32. */
+int aix_pf_build_codes_dev(const uint64_t* d_codes, uint64_t n, int k, int device, void* stream, void** pf_out, uint64_t* pf_len);
 void aix_free(void* p);
 
 /* Roofline probe: n_access uniform-random reads of elem_bytes (4, 8 or 16) over a table

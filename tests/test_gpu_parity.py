@@ -631,3 +631,47 @@ def test_count23_sum_equals_valid_windows_at_scale(canon_case):
     assert (strand == 1).all()
     exp[kid.astype(np.int64)] = counts.cpu().numpy()
     assert np.array_equal(tf.cpu().numpy().astype(np.int64), exp)
+
+
+# ------------------------------------------------------------------------------------------------
+# GPU MWHC builder: a valid emphf .pf (not byte-identical to the reference's), usable end to end
+# ------------------------------------------------------------------------------------------------
+def test_gpu_builder_makes_valid_reference_compatible_pf(tmp_path):
+    import torch
+    from aindex_amd import engine, counting
+    g = engine.synth_genome_t(99, 400_000)
+    keys_t, counts_t = counting.count_distinct_t(g, 23, _lib.CANON_TRUE_RC)
+    pf = builder.build_pf_codes_t(keys_t, 23)
+    keys = keys_t.cpu().numpy().view(np.uint64)
+    host_pf = builder.build_pf_codes(keys, 23)
+    assert len(pf) == len(host_pf) and pf[:32] == host_pf[:32]          # same n, hash domain, seed, bit-pair count
+    path = str(tmp_path / "g.pf")
+    open(path, "wb").write(pf)
+    m = O.OracleMphf(path)                                              # the reference's evaluator (restated) accepts it
+    kmers = synth.decode_kmers(keys, 23)
+    slots = O.lib()  # noqa: F841
+    h = np.array([m.lookup(bytes(k)) for k in kmers[:20000]])
+    assert len(set(h.tolist())) == 20000 and h.max() < keys.shape[0]
+    # full bijection through the GPU evaluator, then the whole query path against the oracle on the same files
+    ix = Index.build_23_codes_t(pf, keys_t, counts_t.to(torch.int32))
+    slots_gpu = ix.hash_ascii(kmers)
+    assert np.array_equal(np.sort(slots_gpu), np.arange(keys.shape[0], dtype=np.uint64))
+    prefix = str(tmp_path / "g")
+    ix.checker_array().tofile(prefix + ".kmers.bin")
+    ix.tf_array().tofile(prefix + ".tf.bin")
+    orc = O.OracleIndex23.from_prefix(prefix)
+    q = np.concatenate([kmers[::7], synth.decode_kmers(synth.revcomp_codes(keys[::11], 23), 23), synth.random_kmers_ascii(5, 20000, 23)])
+    assert np.array_equal(ix.tf_ascii(q), orc.tf_batch(q, threads=8))
+    ref_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref")
+    try:
+        import sys
+        sys.path.insert(0, ref_dir)
+        import aindex_cpp                                               # the compiled reference, when it travelled with the repo
+    except Exception:
+        aindex_cpp = None
+    if aindex_cpp is not None:
+        w = aindex_cpp.AindexWrapper()
+        w.load_from_prefix_23mer(prefix)
+        sub = q[:3000]
+        assert list(w.get_tf_values([bytes(s).decode() for s in sub])) == ix.tf_ascii(sub).tolist()
+    ix.close()
