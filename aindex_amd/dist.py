@@ -16,7 +16,7 @@ def init(backend: str | None = None):
     import torch
     import torch.distributed as dist
     rank, world, local = rank_world()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("AIX_FORCE_DIST")) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         if backend is None:
@@ -56,21 +56,21 @@ def all_reduce_sum_(t):
     """In-place sum over ranks of an integer tensor (tf histograms). int32/int64 carry u32/u64 bit patterns:
     two's-complement addition is the same as unsigned addition modulo 2^32 / 2^64."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("AIX_FORCE_DIST")):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
 
 def barrier():
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("AIX_FORCE_DIST")):
         dist.barrier()
 
 
 def all_reduce_max_float(x: float, device=None) -> float:
     import torch
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("AIX_FORCE_DIST")):
         t = torch.tensor([x], dtype=torch.float64, device=device if device is not None else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())

@@ -30,10 +30,10 @@ for l in open("$O/gather.jsonl"):
 PY
 export TMPDIR=/tmp; cd /tmp
 step "rocprofv3 stats"
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_lookup23 -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary > $O/prof_lookup23.out 2> $O/prof_lookup23.err || exit 8
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_lookup23 -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary --no-gather-probe > $O/prof_lookup23.out 2> $O/prof_lookup23.err || exit 8
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_count13 -- python3 $R/bench.py --workload count13 --steps 3 --warmup 1 > $O/prof_count13.out 2> $O/prof_count13.err || exit 8
 run_pmc () { name=$1; shift; ctrs=$1; shift
-  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $O/pmc/$name -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary "$@" > $O/pmc/$name.out 2> $O/pmc/$name.err || { echo "pmc $name failed"; tail -5 $O/pmc/$name.err; return 1; } }
+  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $O/pmc/$name -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-gather-probe "$@" > $O/pmc/$name.out 2> $O/pmc/$name.err || { echo "pmc $name failed"; tail -5 $O/pmc/$name.err; return 1; } }
 step "pmc lookup23"
 run_pmc l23_fetch "FETCH_SIZE" || exit 9
 run_pmc l23_write "WRITE_SIZE" || exit 9
