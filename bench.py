@@ -201,6 +201,9 @@ def main():
     ap.add_argument("--gpu-builder", action="store_true", help="build the MPHF on the GPU (parallel peeling) instead of the host")
     ap.add_argument("--query-mix", action="store_true", help="Q_mix: 50 %% genome windows on a random strand + 50 %% random (seed 8)")
     a = ap.parse_args()
+    # stdout carries exactly ONE JSON line (rank 0): libraries that print banners to fd 1 (RCCL does at init) go to stderr
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     from aindex_amd import dist as adist, engine, _lib
@@ -423,7 +426,8 @@ def main():
                                  "traffic": None, "kernel": "k_gather", "kernel_ms": kern_ms}})
 
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1 or os.environ.get("AIX_FORCE_DIST"):
         import torch.distributed as dist
         dist.barrier()
