@@ -355,7 +355,9 @@ class AindexWrapper:
 
     # ---- metadata ----------------------------------------------------------------------------
     def get_hash_size(self) -> int:
-        return self._ix23.n if self._ix23 is not None else 0                            # :846-851
+        if self._is_13mer_mode:                                                         # :846-851
+            return TOTAL_13MERS
+        return self._ix23.n if self._ix23 is not None else 0
 
     def get_reads_size(self) -> int:
         return self.reads_size

@@ -675,3 +675,49 @@ def test_gpu_builder_makes_valid_reference_compatible_pf(tmp_path):
         sub = q[:3000]
         assert list(w.get_tf_values([bytes(s).decode() for s in sub])) == ix.tf_ascii(sub).tolist()
     ix.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE config 1 plumbing through the mirrors: count_kmers13 -> AIndex.load_from_prefix(13) -> get_tf_values
+# ------------------------------------------------------------------------------------------------
+def test_config1_plumbing_13mer_through_mirrors(gold, tmp_path):
+    import shutil
+    from pf13 import pf13_path
+    from aindex_amd import tools
+    from aindex_amd.aindex import AIndex
+    prefix = str(tmp_path / "t13")
+    shutil.copy(pf13_path(), prefix + ".pf")
+    fa = os.path.join(gold, "count13", "refdata_test.fasta")
+    assert tools.main(["count_kmers13", fa, prefix + ".pf", prefix + ".tf.bin", "4"]) == 0
+    z = np.load(os.path.join(gold, "count13", "expected.npz"))
+    tf = np.fromfile(prefix + ".tf.bin", dtype=np.uint64)
+    assert tf.shape[0] == 4 ** 13 and np.array_equal(np.nonzero(tf)[0].astype(np.uint64), z["refdata_test.fasta.idx"])
+    ai = AIndex.load_from_prefix(prefix, kmer_size=13)
+    seqs = [ln for ln in open(fa).read().split("\n") if ln and not ln.startswith(">")]
+    wins = [s[i:i + 13] for s in seqs for i in range(len(s) - 12)]
+    got = ai.get_tf_values(wins)
+    assert len(wins) == 12 and got == [1] * 12                       # "twelve 1s"
+    assert ai.get_tf_value(wins[0]) == 1 and ai.get_tf_value(wins[0].lower()) == 0
+    assert ai.get_total_tf_value_13mer(wins[0]) >= 1
+    assert ai.get_sequence_coverage(seqs[0], 0, 13) == [1] * (len(seqs[0]) - 12)
+    assert ai._wrapper.get_tf_by_index_13mer(int(z["refdata_test.fasta.idx"][0])) == 1
+    assert len(ai) == 4 ** 13 and ai.n_kmers == 4 ** 13              # get_hash_size(): TOTAL_13MERS in 13-mer mode (python_wrapper.cpp:846-851)
+
+
+def test_error_codes(small23_prefix, tmp_path):
+    import ctypes as C
+    L = _lib.lib()
+    h = C.c_void_p()
+    assert L.aix_index_open_23(b"/nonexistent.pf", b"/x", b"/y", 0, C.byref(h)) == -2          # AIX_ERR_IO
+    bad = str(tmp_path / "bad.pf")
+    open(bad, "wb").write(open(small23_prefix + ".pf", "rb").read()[:100])
+    assert L.aix_index_open_23(bad.encode(), (small23_prefix + ".tf.bin").encode(), (small23_prefix + ".kmers.bin").encode(), 0, C.byref(h)) == -3
+    with pytest.raises(FileNotFoundError):
+        from aindex_amd.wrapper import AindexWrapper
+        AindexWrapper().load_from_prefix_23mer("/nonexistent/prefix")
+    with Index.open_23(small23_prefix + ".pf", small23_prefix + ".tf.bin", small23_prefix + ".kmers.bin") as ix:
+        out = np.zeros(4 ** 13, dtype=np.uint64)
+        assert L.aix_count13(ix._h, None, 0, 0, out.ctypes.data_as(C.c_void_p)) == -7           # AIX_ERR_MODE
+        assert L.aix_tf_batch_ascii(ix._h, None, 5, None) == -1                                  # AIX_ERR_ARG
+    assert L.aix_index_open_23(small23_prefix.encode() + b".pf", (small23_prefix + ".tf.bin").encode(), (small23_prefix + ".kmers.bin").encode(), 99,
+                               C.byref(h)) == -1                                                 # no such device
