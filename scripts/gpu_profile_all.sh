@@ -12,10 +12,12 @@ step "bench default"
 timeout -k 10 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err || { tail -20 $O/bench_default.err; exit 5; }
 echo "bench default wall $(( $(date +%s) - ts )) s" | tee -a $O/progress.txt; cat $O/bench_default.json
 step "secondary workloads"
-for w in "lookup23 --no-fingerprint --no-cpu-baseline" "lookup23 --no-fastpath --no-cpu-baseline" "lookup13" "count13" "count23 --reads 2000000" "coverage23"; do
-  n=$(echo $w | tr -d ' -'); timeout -k 10 600 python bench.py --workload $w --steps 5 --warmup 1 > $O/bench_$n.json 2> $O/bench_$n.err || { echo "$w failed"; tail -10 $O/bench_$n.err; exit 6; }
+for w in "lookup23 --no-fingerprint --no-cpu-baseline --no-secondary --no-gather-probe" "lookup23 --no-fastpath --no-cpu-baseline --no-secondary --no-gather-probe" "lookup23 --query-mix --cpu-sample 2000000 --no-secondary --no-gather-probe" "lookup23 --gpu-builder --no-cpu-baseline --no-secondary --no-gather-probe" "lookup13" "count13" "count23 --reads 2000000" "coverage23" "positions23 --reads 5000000" "normalize --reads 5000000"; do
+  n=$(echo $w | sed 's/--no-cpu-baseline//; s/--no-secondary//; s/--no-gather-probe//; s/--cpu-sample 2000000//' | tr -d ' -'); timeout -k 10 600 python bench.py --workload $w --steps 5 --warmup 1 > $O/bench_$n.json 2> $O/bench_$n.err || { echo "$w failed"; tail -10 $O/bench_$n.err; exit 6; }
 done
 AIX_COUNT13_ATOMICS=1 timeout -k 10 600 python bench.py --workload count13 --steps 3 --warmup 1 > $O/bench_count13_atomics.json 2> /dev/null || exit 6
+timeout -k 10 600 python scripts/gpu_hostpath.py > $O/hostpath.json 2> $O/hostpath.err || { echo hostpath failed; tail -5 $O/hostpath.err; exit 6; }
+grep -h "index:" $O/bench_lookup23gpubuilder.err $O/bench_default.err | tee -a $O/progress.txt
 step "gather probes"
 rm -f $O/gather.jsonl
 for cfg in "16384 16 1" "4096 16 1" "800 16 1" "61 16 1" "31 16 1" "2 16 1" "4096 8 1" "4096 16 4"; do set -- $cfg
@@ -24,7 +26,7 @@ done
 python - <<PY
 import json,glob
 for f in sorted(glob.glob("$O/bench_*.json")):
-    d=json.load(open(f)); print(f.split("/")[-1], d["metric"], "%.4g %s" % (d["value"], d["unit"]), "kernel_ms %.3f" % d["roofline"]["kernel_ms"])
+    d=json.load(open(f)); print(f.split("/")[-1], d["metric"], "%.4g %s" % (d["value"], d["unit"]), "kernel_ms %.3f" % (d["roofline"]["kernel_ms"] or 0))
 for l in open("$O/gather.jsonl"):
     d=json.loads(l); print(d["config"]["workload"], "%.1f G acc/s" % (d["value"]/1e9))
 PY
