@@ -721,3 +721,31 @@ def test_error_codes(small23_prefix, tmp_path):
         assert L.aix_tf_batch_ascii(ix._h, None, 5, None) == -1                                  # AIX_ERR_ARG
     assert L.aix_index_open_23(small23_prefix.encode() + b".pf", (small23_prefix + ".tf.bin").encode(), (small23_prefix + ".kmers.bin").encode(), 99,
                                C.byref(h)) == -1                                                 # no such device
+
+
+def test_count13_skewed_and_crlf_inputs(ix13):
+    """Extreme partition skew (homopolymers, short tandem repeats) and CRLF / mixed-case records."""
+    from pf13 import pf13_path
+    m = O.OracleMphf(pf13_path())
+    rng = np.random.default_rng(11)
+    lines = []
+    for i in range(4000):
+        kind = i % 5
+        if kind == 0:
+            lines.append(b"A" * 150)
+        elif kind == 1:
+            lines.append(b"T" * 70 + b"N" + b"T" * 79)
+        elif kind == 2:
+            lines.append(b"ACG" * 50)
+        elif kind == 3:
+            lines.append(bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 150)))
+        else:
+            lines.append(bytes(rng.choice(np.frombuffer(b"acgtACGTnRY", dtype=np.uint8), 150)))
+    plain = b"\n".join(lines) + b"\n"
+    got = ix13.count13(plain, _lib.FMT_PLAIN)
+    assert np.array_equal(got, O.count13(m, plain, 0, threads=8))
+    assert int(got.max()) >= 800 * 138                                 # the poly-A bin
+    fq = b"".join(b"@r%d\r\n" % i + ln + b"\r\n+\r\n" + b"I" * len(ln) + b"\r\n" for i, ln in enumerate(lines[:500]))
+    assert np.array_equal(ix13.count13(fq), O.count13(m, fq, -1))      # '\r' stays in the sequence line -> breaks windows
+    fa = b"".join(b">s%d\r\n" % i + ln[:75] + b"\r\n" + ln[75:] + b"\r\n" for i, ln in enumerate(lines[:500]))
+    assert np.array_equal(ix13.count13(fa), O.count13(m, fa, -1))
