@@ -18,36 +18,6 @@ static inline unsigned grid_for(uint64_t work, unsigned per_block = kBlock) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// unaligned window loads. Every dword that is read contains at least one byte of the window, so a
-// window that lies inside the caller's buffer can never fault, whatever the buffer's alignment.
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void load23(const uint8_t* p, uint64_t& w0, uint64_t& w1, uint64_t& w2) {
-    const uintptr_t a = (uintptr_t)p;
-    const uint32_t o = (uint32_t)(a & 3);
-    const uint32_t* q = (const uint32_t*)(a - o);
-    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4], d5 = q[5];
-    const uint32_t d6 = (o >= 2) ? q[6] : 0u;        // bytes 20..22 reach dword 6 only when o >= 2
-    const uint32_t sh = o * 8;
-    const uint32_t e0 = __funnelshift_r(d0, d1, sh), e1 = __funnelshift_r(d1, d2, sh);
-    const uint32_t e2 = __funnelshift_r(d2, d3, sh), e3 = __funnelshift_r(d3, d4, sh);
-    const uint32_t e4 = __funnelshift_r(d4, d5, sh), e5 = __funnelshift_r(d5, d6, sh) & 0x00FFFFFFu;
-    w0 = e0 | ((uint64_t)e1 << 32);
-    w1 = e2 | ((uint64_t)e3 << 32);
-    w2 = e4 | ((uint64_t)e5 << 32);
-}
-__device__ __forceinline__ void load13(const uint8_t* p, uint64_t& w0, uint64_t& w1) {
-    const uintptr_t a = (uintptr_t)p;
-    const uint32_t o = (uint32_t)(a & 3);
-    const uint32_t* q = (const uint32_t*)(a - o);
-    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3];   // byte 12 lies in dword 3 for every o
-    const uint32_t sh = o * 8;
-    const uint32_t e0 = __funnelshift_r(d0, d1, sh), e1 = __funnelshift_r(d1, d2, sh);
-    const uint32_t e2 = __funnelshift_r(d2, d3, sh), e3 = __funnelshift_r(d3, 0u, sh) & 0x000000FFu;
-    w0 = e0 | ((uint64_t)e1 << 32);
-    w1 = e2 | ((uint64_t)e3 << 32);
-}
-
-// ---------------------------------------------------------------------------------------------
 // probes
 // ---------------------------------------------------------------------------------------------
 struct Probe {

@@ -22,20 +22,6 @@ static inline unsigned grid_of(uint64_t work) {
     return (unsigned)b;
 }
 
-__device__ __forceinline__ void ld23(const uint8_t* p, uint64_t& w0, uint64_t& w1, uint64_t& w2) {
-    const uintptr_t a = (uintptr_t)p;
-    const uint32_t o = (uint32_t)(a & 3);
-    const uint32_t* q = (const uint32_t*)(a - o);
-    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4], d5 = q[5];
-    const uint32_t d6 = (o >= 2) ? q[6] : 0u;
-    const uint32_t sh = o * 8;
-    const uint32_t e0 = __funnelshift_r(d0, d1, sh), e1 = __funnelshift_r(d1, d2, sh);
-    const uint32_t e2 = __funnelshift_r(d2, d3, sh), e3 = __funnelshift_r(d3, d4, sh);
-    const uint32_t e4 = __funnelshift_r(d4, d5, sh), e5 = __funnelshift_r(d5, d6, sh) & 0x00FFFFFFu;
-    w0 = e0 | ((uint64_t)e1 << 32);
-    w1 = e2 | ((uint64_t)e3 << 32);
-    w2 = e4 | ((uint64_t)e5 << 32);
-}
 // any byte of x (restricted to `mask` bytes) equal to c ?
 __device__ __forceinline__ bool has_byte(uint64_t x, uint8_t c, uint64_t mask) {
     const uint64_t z = (x ^ (0x0101010101010101ULL * c)) | ~mask;
@@ -55,7 +41,7 @@ __global__ void __launch_bounds__(kB) k_a2_probe(const IndexDev ix, const uint8_
         uint32_t key = (uint32_t)ix.n;
         if (i >= start) {
             uint64_t w0, w1, w2;
-            ld23(buf + i, w0, w1, w2);
+            load23(buf + i, w0, w1, w2);
             const bool skip = has_byte(w0, '\n', FULL) || has_byte(w1, '\n', FULL) || has_byte(w2, '\n', LAST7) ||
                               has_byte(w0, '~', FULL) || has_byte(w1, '~', FULL) || has_byte(w2, '~', LAST7) ||
                               has_byte(w0, 'N', FULL) || has_byte(w1, 'N', FULL) || has_byte(w2, 'N', LAST7);      // :1006-1011

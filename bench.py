@@ -259,6 +259,10 @@ def main():
                                               "accesses_per_query": lines_per_query,
                                               "note": "peak = k_gather, uniform-random 16-byte reads over a 4 GiB table in HBM (SURVEY 8d-ii); most of the "
                                                       "lookup's accesses hit the 61 MB MPHF table in the Infinity Cache, hence frac can exceed 1"}
+        # BASELINE.json.published is {}; the reference's README figure is kept for orientation only (hardware unstated,
+        # measured through Python list[str] on an unshipped index), so vs_baseline stays null
+        out["published_reference_rate"] = {"value": 2.3e6, "unit": "lookups/s", "source": "reference README.md:14,480,596 (BASELINE.md section 1)",
+                                           "ratio": value / 2.3e6}
         tr = load_pmc_traffic("lookup23")
         if tr:
             out["roofline"]["traffic"] = tr.get("bytes_per_launch")
