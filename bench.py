@@ -168,6 +168,94 @@ def gather_roofline(dev, table_mib=4096, accesses=200_000_000, reps=3):
     return accesses / (ms * 1e-3)
 
 
+def cpu_baseline_count13(ix, reads_t, n_sample, tmpdir, pf13):
+    """count_kmers13 on the host for a bounded sample of the same reads: the compiled reference binary (all cores, its
+    own "Processing completed" time) when oracle/_ref is present, and our C port; both compared with the GPU result."""
+    import re
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    os.makedirs(tmpdir, exist_ok=True)
+    sample_t = reads_t[: n_sample * 151]
+    gpu = ix.count13_t(sample_t).cpu().numpy().view(np.uint64)
+    host = sample_t.cpu().numpy().tobytes()
+    ncores = os.cpu_count() or 1
+    res = {}
+    m = O.OracleMphf(pf13)
+    for name, th in (("port_1t", 1), ("port_mt", min(ncores, 64))):
+        ns = n_sample if th > 1 else max(1, n_sample // 8)
+        buf = host[: ns * 151]
+        t = time.perf_counter(); got = O.count13(m, buf, 0, threads=th); dt = time.perf_counter() - t
+        if ns == n_sample:
+            assert np.array_equal(got, gpu), "CPU port and GPU disagree on the sample"
+        res[name] = {"value": ns / dt, "unit": "reads/s", "cores": th, "kind": "port", "sample": f"first {ns} reads of the batch"}
+    exe = os.path.join(ROOT, "oracle", "_ref", "count_kmers13")
+    if os.path.exists(exe):
+        inp, outp = os.path.join(tmpdir, "sample.txt"), os.path.join(tmpdir, "sample.tf.bin")
+        open(inp, "wb").write(host)
+        try:
+            r = subprocess.run([exe, inp, pf13, outp], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
+            mm = re.search(rb"Processing completed in (\d+) ms", r.stdout)
+            ref = np.fromfile(outp, dtype=np.uint64)
+            assert np.array_equal(ref, gpu), "reference count_kmers13 and GPU disagree on the sample"
+            if mm and int(mm.group(1)) > 0:
+                res["reference"] = {"value": n_sample / (int(mm.group(1)) * 1e-3), "unit": "reads/s", "cores": ncores, "kind": "reference",
+                                    "sample": f"first {n_sample} reads of the batch through oracle/_ref/count_kmers13 (its own processing time)"}
+        except Exception as e:
+            log(f"cpu_baseline: reference count_kmers13 not usable ({type(e).__name__}: {e})")
+        for f in (inp, outp):
+            try:
+                os.remove(f)
+            except OSError:
+                pass
+    return res
+
+
+def cpu_baseline_coverage23(ix, pf, seqs_t, L, out_t, per, n_seq, tmpdir):
+    """The reference's coverage path — AIndex.get_sequence_coverage's Python loop (aindex/core/aindex.py:314-322) over
+    aindex_cpp.get_tf_value — on a few sequences of the batch, compared with the GPU profile."""
+    os.makedirs(tmpdir, exist_ok=True)
+    prefix = os.path.join(tmpdir, "cov23")
+    open(prefix + ".pf", "wb").write(pf)
+    ix.tf_array().tofile(prefix + ".tf.bin")
+    ix.checker_array().tofile(prefix + ".kmers.bin")
+    res = None
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "oracle", "_ref"))
+        import aindex_cpp
+        w = aindex_cpp.AindexWrapper()
+        devnull = os.open(os.devnull, os.O_WRONLY)
+        se = os.dup(2)
+        os.dup2(devnull, 2)
+        try:
+            w.load_from_prefix_23mer(prefix)
+        finally:
+            os.dup2(se, 2)
+        host = seqs_t[: n_seq * (L + 1)].cpu().numpy().reshape(n_seq, L + 1)
+        gpu = out_t[: n_seq * per].cpu().numpy().view(np.uint32).reshape(n_seq, per)
+        t = time.perf_counter()
+        for i in range(n_seq):
+            s = bytes(host[i, :L]).decode()
+            cov = [0] * (len(s) - 23 + 1)
+            for j in range(len(s) - 23 + 1):
+                tf = w.get_tf_value(s[j:j + 23])
+                if tf >= 0:
+                    cov[j] = tf
+            if i < 4:
+                assert cov == gpu[i, : L - 22].tolist(), "reference coverage loop and GPU disagree"
+        dt = time.perf_counter() - t
+        res = {"value": n_seq / dt, "unit": "sequences/s", "cores": 1, "kind": "reference",
+               "sample": f"first {n_seq} sequences of the batch through the reference's Python loop over aindex_cpp.get_tf_value"}
+    except Exception as e:
+        log(f"cpu_baseline: reference coverage not usable ({type(e).__name__}: {e})")
+    for f in (".pf", ".tf.bin", ".kmers.bin"):
+        try:
+            os.remove(prefix + f)
+        except OSError:
+            pass
+    return res
+
+
 def load_pmc_traffic(workload):
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
@@ -192,6 +280,7 @@ def main():
     ap.add_argument("--genome", type=int, default=50_000_000)
     ap.add_argument("--reads", type=int, default=10_000_000)
     ap.add_argument("--cpu-sample", type=int, default=20_000_000)
+    ap.add_argument("--cpu-reads", type=int, default=400_000, help="reads in the bounded CPU sample of the counting workloads")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather-probe", action="store_true", help="skip the live random-read roofline measurement")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary counting measurement of the default workload")
@@ -331,9 +420,13 @@ def main():
         wall, kern_ms, _ = timed_steps(step, a.steps, a.warmup, dev)
         windows = a.reads * (150 - 12)
         achieved = (a.reads * 151 + windows * 8.0) / (kern_ms * 1e-3) / 1e9
+        cb = None
+        if rank == 0 and world == 1 and not a.no_cpu_baseline:
+            cb = cpu_baseline_count13(ix, reads, min(a.cpu_reads, a.reads), os.path.join(cache, "cpu13"), pf13_path())
         out.update({"metric": "reads_per_sec_13mer_count", "value": world * a.reads * a.steps / wall, "unit": "reads/s",
                     "ms_per_step": wall / a.steps * 1e3, "dtype": "u64",
                     "config": {"workload": "configs[1]: 13-mer dense 4^13 table count of 150 bp reads + all-reduce", "reads_per_step_per_gpu": a.reads},
+                    **({"cpu_baseline": cb.get("reference", cb["port_mt"]), "cpu_baseline_extra": cb} if cb else {}),
                     "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                  "traffic": None, "kernel": "k_count13 (+memset, scatter)", "kernel_ms": kern_ms}})
 
@@ -367,10 +460,14 @@ def main():
         wall, kern_ms, _ = timed_steps(step, a.steps, a.warmup, dev)
         positions = a.seqs * per
         achieved = positions * (1.0 + 100.0 + 4.0 + 4.0) / (kern_ms * 1e-3) / 1e9
+        cb = None
+        if rank == 0 and world == 1 and not a.no_cpu_baseline:
+            cb = cpu_baseline_coverage23(ix, pf, seqs, L, outp, per, 40, os.path.join(cache, "cpucov"))
         out.update({"metric": "sequences_per_sec_coverage_23mer", "value": world * a.seqs * a.steps / wall, "unit": "sequences/s",
                     "ms_per_step": wall / a.steps * 1e3, "dtype": "u64",
                     "config": {"workload": f"configs[4]: per-position tf profile (k=23) of {L} bp sequences drawn from the indexed genome (50 % rc, 0.1 % N)",
                                "sequences_per_step_per_gpu": a.seqs, "positions_per_step": positions, "nonzero_fraction": float((outp != 0).float().mean().item())},
+                    **({"cpu_baseline": cb} if cb else {}),
                     "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                  "traffic": None, "kernel": "k_coverage", "kernel_ms": kern_ms, "positions_per_sec": positions / (kern_ms * 1e-3)}})
 
