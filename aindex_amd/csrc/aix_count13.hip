@@ -249,15 +249,13 @@ hipError_t launch_count13_partitioned(const uint8_t* buf, uint64_t len, void* wo
     uint16_t* parts = (uint16_t*)(((uintptr_t)(cnt + (uint64_t)C13_P * C13_MAXGRID) + 15) & ~(uintptr_t)15);   // 16-byte aligned for uint4 loads
     const uint64_t ntiles = (nwin + C13_TILE - 1) / C13_TILE;
     const unsigned grid = (unsigned)std::min<uint64_t>(ntiles ? ntiles : 1, C13_MAXGRID);
-    static bool attr_set = false;
     const size_t hist_lds = 4 * C13_BINS;                                   // 131 072 B
     const size_t split_lds = 4 * (3 * C13_P + 16) + 4 * C13_TILE;           // 155 712 B
-    if (!attr_set) {
+    {   // > 64 KiB of dynamic LDS needs the attribute; set per call (cheap, and correct for every device / thread)
         hipError_t e = hipFuncSetAttribute((const void*)k_c13_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds);
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute((const void*)k_c13_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)split_lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     hipLaunchKernelGGL(k_c13_sizes, dim3(grid), dim3(C13_TB), 0, s, buf, len, ntiles, cnt);
     hipLaunchKernelGGL(k_c13_colscan, dim3(C13_P / C13_TB), dim3(C13_TB), 0, s, cnt, grid, part_count);

@@ -8,7 +8,7 @@ All results are bit-exact with the reference's CPU implementation (see tests/).
 from __future__ import annotations
 
 import ctypes as C
-from typing import Iterable, Optional, Sequence, Tuple
+from typing import Optional, Sequence, Tuple
 
 import numpy as np
 
