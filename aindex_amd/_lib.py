@@ -52,6 +52,7 @@ SIGNATURES = {
     "aix_index_info": (i32, [vp, C.POINTER(Info)]),
     "aix_index_set_canonical_fastpath": (i32, [vp, i32]),
     "aix_index_set_fingerprint_filter": (i32, [vp, i32]),
+    "aix_index_set_early_exit": (i32, [vp, i32]),
     "aix_index_set_tf_13": (i32, [vp, vp]),
     "aix_index_get_tf": (i32, [vp, vp, u64]),
     "aix_index_get_checker": (i32, [vp, vp, u64]),
@@ -61,6 +62,7 @@ SIGNATURES = {
     "aix_tf_batch_codes_dev": (i32, [vp, vp, u64, vp, vp]),
     "aix_tf_batch_ragged": (i32, [vp, vp, vp, u64, vp]),
     "aix_tf_batch_ragged_dev": (i32, [vp, vp, vp, u64, vp, vp]),
+    "aix_lines_batch_ascii_dev": (i32, [vp, vp, u64, vp, vp]),
     "aix_hash_batch_ascii": (i32, [vp, vp, u64, vp]),
     "aix_hash_batch_ascii_dev": (i32, [vp, vp, u64, vp, vp]),
     "aix_kid_strand_batch_ascii": (i32, [vp, vp, u64, vp, vp]),

@@ -67,6 +67,7 @@ struct aix_index {
     bool canonical_fastpath = true;
     bool has_fp = false;
     bool fp_filter = true;
+    bool early_exit = true;
     std::mutex count_mutex;
 
     IndexDev dev() const {
@@ -83,6 +84,7 @@ struct aix_index {
         d.canonical_only = (canonical_only && canonical_fastpath) ? 1u : 0u;
         d.k = k;
         d.use_fp = (has_fp && fp_filter) ? 1u : 0u;
+        d.early_exit = (has_fp && fp_filter && early_exit) ? 1u : 0u;
         return d;
     }
 };
@@ -167,6 +169,7 @@ static int upload_mphf(aix_index* h, const uint8_t* pf, uint64_t len) {
         recs[i].pairs = half;
         recs[i].prefix = (uint32_t)run;
         recs[i].fp = 0;
+        recs[i].present[0] = recs[i].present[1] = recs[i].present[2] = recs[i].present[3] = 0;
         run += (uint32_t)__builtin_popcount((half | (half >> 1)) & 0x55555555u);
     }
     if (run >> 32) return AIX_ERR_UNSUPPORTED;
@@ -405,6 +408,12 @@ extern "C" int aix_index_set_fingerprint_filter(aix_index_t* h, int enabled) {
     return AIX_OK;
 }
 
+extern "C" int aix_index_set_early_exit(aix_index_t* h, int enabled) {
+    if (!h) return AIX_ERR_ARG;
+    h->early_exit = enabled != 0;
+    return AIX_OK;
+}
+
 extern "C" int aix_index_set_tf_13(aix_index_t* h, const uint64_t* tf) {
     if (!h || !tf) return AIX_ERR_ARG;
     if (h->k != 13) return AIX_ERR_MODE;
@@ -474,6 +483,14 @@ extern "C" int aix_tf_batch_ascii_dev(aix_index_t* h, const char* d_kmers, uint6
     LookupOut o{};
     o.tf = d_out;
     return lookup_ascii_dev(h, d_kmers, N, MODE_TF, o, stream);
+}
+// instrumentation: d_out[i] = number of MPHF + key records the tf query i reads under the handle's current settings
+extern "C" int aix_lines_batch_ascii_dev(aix_index_t* h, const char* d_kmers, uint64_t N, uint32_t* d_out, void* stream) {
+    if (N && !d_out) return AIX_ERR_ARG;
+    if (h && h->k != 23) return AIX_ERR_MODE;
+    LookupOut o{};
+    o.tf = d_out;
+    return lookup_ascii_dev(h, d_kmers, N, MODE_LINES, o, stream);
 }
 extern "C" int aix_hash_batch_ascii_dev(aix_index_t* h, const char* d_kmers, uint64_t N, uint64_t* d_out, void* stream) {
     if (N && !d_out) return AIX_ERR_ARG;

@@ -17,10 +17,10 @@ struct IndexDev {
     uint32_t canonical_only;  // 23-mer: every stored code <= its reverse complement
     uint32_t k;
     uint32_t use_fp;          // 23-mer: the fingerprint nibbles of the MPHF records are populated
-    uint32_t pad_;
+    uint32_t early_exit;      // 23-mer: presence masks populated and the early-exit walk enabled
 };
 
-enum LookupMode { MODE_TF = 0, MODE_HASH = 1, MODE_KIDSTRAND = 2, MODE_BOTH = 3, MODE_TOTAL = 4 };
+enum LookupMode { MODE_TF = 0, MODE_HASH = 1, MODE_KIDSTRAND = 2, MODE_BOTH = 3, MODE_TOTAL = 4, MODE_LINES = 5 };
 
 struct LookupOut {
     uint32_t* tf;       // MODE_TF

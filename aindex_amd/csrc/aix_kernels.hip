@@ -23,6 +23,7 @@ static inline unsigned grid_for(uint64_t work, unsigned per_block = kBlock) {
 struct Probe {
     uint64_t slot;
     uint32_t tf;
+    uint32_t lines;     // instrumentation for MODE_LINES: MPHF records read | 16 per key record read | 256 per completed evaluation
     bool found;
 };
 // hash the 23 ASCII bytes in (w0,w1,w2), evaluate the MPHF, verify against the stored code
@@ -32,16 +33,26 @@ __device__ __forceinline__ Probe probe23(const IndexDev& ix, uint64_t w0, uint64
     Probe r;
     r.found = false;
     r.tf = 0;
-    if (ix.use_fp) {
+    r.slot = 0;
+    r.lines = 3;
+    if (ix.early_exit) {
+        uint32_t fps;
+        if (!mphf_probe_early_exit(ix.m, a, b, c, r.slot, fps, r.lines)) return r;   // a node lacks the key's presence bit
+        r.lines += 256;
+        if (fps != fp_of_hash(a, b, c)) return r;
+    } else if (ix.use_fp) {
+        r.lines += 256;
         uint32_t fps;
         uint64_t node;
         r.slot = mphf_from_hash_fp(ix.m, a, b, c, fps, node);
         if (fps != fp_of_hash(a, b, c)) return r;  // the key assigned to this node (if any) is a different key
     } else {
+        r.lines += 256;
         r.slot = mphf_from_hash(ix.m, a, b, c);
     }
     if (r.slot < ix.n) {                           // python_wrapper.cpp:613 `h1 >= n ||`
         const KeyRec k = ix.keys[r.slot];
+        r.lines += 16;
         if (k.code == code) { r.found = true; r.tf = k.tf; }
     }
     return r;
@@ -52,8 +63,10 @@ __device__ __forceinline__ Probe probe23_hashed(const IndexDev& ix, uint64_t a, 
     r.slot = mphf_from_hash(ix.m, a, b, c);
     r.found = false;
     r.tf = 0;
+    r.lines = 3 + 256;
     if (r.slot < ix.n) {
         const KeyRec k = ix.keys[r.slot];
+        r.lines += 16;
         if (k.code == code) { r.found = true; r.tf = k.tf; }
     }
     return r;
@@ -64,31 +77,36 @@ struct Q23 {
     uint64_t slot;
     uint32_t tf;
     uint32_t strand;
+    uint32_t lines;
 };
 template <bool CANON>
 __device__ __forceinline__ Q23 query23(const IndexDev& ix, uint64_t w0, uint64_t w1, uint64_t w2) {
     const Enc23 e = encode23_words(w0, w1, w2);
     const uint64_t r = revcomp(e.code, 23);
     Q23 out;
-    out.slot = 0; out.tf = 0; out.strand = 0;
+    out.slot = 0; out.tf = 0; out.strand = 0; out.lines = 0;
     if (CANON && e.valid) {
         // every stored code is canonical: only the canonical strand of the query can match
         if (e.code <= r) {
             const Probe p = probe23(ix, w0, w1, w2, e.code);
+            out.lines = p.lines;
             if (p.found) { out.slot = p.slot; out.tf = p.tf; out.strand = 1; }
         } else {
             uint64_t r0, r1, r2;
             ascii23_of_rc(e.code, r0, r1, r2);
             const Probe p = probe23(ix, r0, r1, r2, r);
+            out.lines = p.lines;
             if (p.found) { out.slot = p.slot; out.tf = p.tf; out.strand = 2; }
         }
         return out;
     }
     const Probe f = probe23(ix, w0, w1, w2, e.code);           // raw bytes hashed, sanitised code compared
+    out.lines = f.lines;
     if (f.found) { out.slot = f.slot; out.tf = f.tf; out.strand = 1; return out; }
     uint64_t r0, r1, r2;
     ascii23_of_rc(e.code, r0, r1, r2);                          // decode(reverseDNA(u)), :615-616
     const Probe g = probe23(ix, r0, r1, r2, r);
+    out.lines += g.lines;
     if (g.found) { out.slot = g.slot; out.tf = g.tf; out.strand = 2; }
     return out;
 }
@@ -125,6 +143,8 @@ __global__ void __launch_bounds__(kBlock) k_lookup23_ascii(const IndexDev ix, co
         load23(q + 23 * i, w0, w1, w2);
         if (MODE == MODE_TF) {
             out.tf[i] = query23<CANON>(ix, w0, w1, w2).tf;
+        } else if (MODE == MODE_LINES) {
+            out.tf[i] = query23<CANON>(ix, w0, w1, w2).lines;   // instrumentation: records read for this query
         } else if (MODE == MODE_HASH) {
             uint64_t a, b, c;
             jenkins23(w0, w1, w2, ix.m.seed, a, b, c);
@@ -343,6 +363,12 @@ __global__ void __launch_bounds__(kBlock) k_set_fp(const MphfDev m, BvRec* __res
         jenkins23(w0, w1, w2, m.seed, a, b, c);
         if (mphf_from_hash_fp(m, a, b, c, fps, node) != i) continue;
         atomicOr((unsigned long long*)&recs[node >> 4].fp, (unsigned long long)fp_of_hash(a, b, c) << (4 * (uint32_t)(node & 15)));
+        const uint64_t nd[3] = {fastmod(a, m.fm), m.D + fastmod(b, m.fm), 2 * m.D + fastmod(c, m.fm)};
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {                     // presence bit of this key at each of its three nodes
+            const uint32_t j = (uint32_t)(nd[t] & 15);
+            atomicOr(&recs[nd[t] >> 4].present[j >> 2], 1u << (8 * (j & 3) + present_bit(a, b, c, t)));
+        }
     }
 }
 
@@ -428,7 +454,8 @@ __global__ void __launch_bounds__(kBlock) k_count23_fixed(const IndexDev ix, con
     if (len < 23) return;
     const uint64_t nwin = len - 22;
     IndexDev ixn = ix;
-    ixn.use_fp = 0;               // windows of reads drawn from the indexed genome are hits: the filter only costs
+    ixn.use_fp = 0;               // windows of reads drawn from the indexed genome are hits: the filters only cost
+    ixn.early_exit = 0;
     for (uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x; p < nwin; p += stride) {
         uint64_t w0, w1, w2;
         load23(buf + p, w0, w1, w2);
@@ -579,7 +606,7 @@ __global__ void __launch_bounds__(kBlock) k_gather(const uint8_t* __restrict__ t
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             if (ELEM == 16) {
-                const BvRec r = ((const BvRec*)table)[idx[u]];
+                const BvHead r = ((const BvHead*)table)[idx[u]];
                 acc += r.fp ^ r.prefix;
             } else if (ELEM == 8) {
                 acc += ((const uint64_t*)table)[idx[u]];
@@ -604,6 +631,7 @@ template <bool CANON>
 static hipError_t lookup23_ascii_mode(const IndexDev& ix, const uint8_t* q, uint64_t N, int mode, LookupOut out, hipStream_t s) {
     switch (mode) {
         case MODE_TF: AIX_LAUNCH((k_lookup23_ascii<MODE_TF, CANON>), N, s, ix, q, N, out);
+        case MODE_LINES: AIX_LAUNCH((k_lookup23_ascii<MODE_LINES, CANON>), N, s, ix, q, N, out);
         case MODE_HASH: AIX_LAUNCH((k_lookup23_ascii<MODE_HASH, CANON>), N, s, ix, q, N, out);
         case MODE_KIDSTRAND: AIX_LAUNCH((k_lookup23_ascii<MODE_KIDSTRAND, CANON>), N, s, ix, q, N, out);
         case MODE_BOTH: AIX_LAUNCH((k_lookup23_ascii<MODE_BOTH, CANON>), N, s, ix, q, N, out);

@@ -146,6 +146,9 @@ class Index:
     def set_fingerprint_filter(self, enabled: bool):
         check(lib().aix_index_set_fingerprint_filter(self._h, int(enabled)))
 
+    def set_early_exit(self, enabled: bool):
+        check(lib().aix_index_set_early_exit(self._h, int(enabled)))
+
     def set_tf_13(self, tf: np.ndarray):
         tf = np.ascontiguousarray(tf, dtype=np.uint64)
         assert tf.shape[0] == _lib.TOTAL_13MERS
@@ -263,6 +266,15 @@ class Index:
             out_t = torch.empty(n, dtype=torch.int32, device=kmers_t.device)   # u32 bit patterns
         check(lib().aix_tf_batch_ascii_dev(self._h, vp(kmers_t.data_ptr()), n, vp(out_t.data_ptr()), _stream_ptr()),
               "aix_tf_batch_ascii_dev")
+        return out_t
+
+    def lines_ascii_t(self, kmers_t):
+        """Instrumentation: records (128-byte lines) each tf query reads under the current settings."""
+        import torch
+        self._chk_dev(kmers_t)
+        n = kmers_t.numel() // self.k
+        out_t = torch.empty(n, dtype=torch.int32, device=kmers_t.device)
+        check(lib().aix_lines_batch_ascii_dev(self._h, vp(kmers_t.data_ptr()), n, vp(out_t.data_ptr()), _stream_ptr()), "aix_lines_batch_ascii_dev")
         return out_t
 
     def tf_codes_t(self, codes_t, out_t=None):

@@ -287,6 +287,7 @@ def main():
     ap.add_argument("--reads23", type=int, default=2_000_000)
     ap.add_argument("--no-fastpath", action="store_true", help="force the reference's two-probe order")
     ap.add_argument("--no-fingerprint", action="store_true", help="disable the 4-bit fingerprint filter")
+    ap.add_argument("--no-early-exit", action="store_true", help="disable the early-exit MPHF walk (presence masks)")
     ap.add_argument("--gpu-builder", action="store_true", help="build the MPHF on the GPU (parallel peeling) instead of the host")
     ap.add_argument("--query-mix", action="store_true", help="Q_mix: 50 %% genome windows on a random strand + 50 %% random (seed 8)")
     a = ap.parse_args()
@@ -313,6 +314,8 @@ def main():
             ix.set_canonical_fastpath(False)
         if a.no_fingerprint:
             ix.set_fingerprint_filter(False)
+        if a.no_early_exit:
+            ix.set_early_exit(False)
         if a.query_mix:
             q = engine.synth_mix23_t(8, g, a.queries, first=rank * a.queries)
         else:
@@ -326,7 +329,7 @@ def main():
         # checker reads: every probe without the fingerprint filter; with it only hits + 1/16 of the failing probes
         checker_reads = probes if a.no_fingerprint else hf + (probes - hf) / 16.0
         # one MPHF evaluation E = 92 B, + 8 B per checker read, + 4 B tf per hit, + 27 B streamed per query
-        bytes_per_query = 27.0 + probes * 92.0 + checker_reads * 8.0 + 4.0 * hf
+        bytes_per_query = 27.0 + probes * 92.0 + checker_reads * 8.0 + 4.0 * hf          # full evaluations
         achieved = bytes_per_query * a.queries / (kern_ms * 1e-3) / 1e9
         value = world * a.queries * a.steps / wall
         out.update({"metric": "kmer_lookups_per_sec_23mer_batch", "value": value, "unit": "lookups/s",
@@ -339,9 +342,24 @@ def main():
                     "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                  "traffic": None, "kernel": "k_lookup23_ascii", "kernel_ms": kern_ms,
                                  "algorithmic_bytes_per_query": bytes_per_query}})
+        # what the kernel actually touches (instrumented launch of the same kernel, same settings): MPHF records read,
+        # key records read and evaluations carried through to the rank, per query
+        li = ix.lines_ascii_t(q).to(torch.int64)
+        mphf_recs = float((li & 15).sum().item()) / a.queries
+        key_recs = float(((li >> 4) & 15).sum().item()) / a.queries
+        completed = float((li >> 8).sum().item()) / a.queries
+        del li
+        lines_per_query = mphf_recs + key_recs
+        # SURVEY 8(d) per-unit figures: 8 B per bit-pair word read, 8 B block rank + 60 B scan per completed evaluation,
+        # 8 B per checker read, 4 B tf per hit, 27 B streamed per query
+        bytes_per_query = 27.0 + 8.0 * mphf_recs + 68.0 * completed + 8.0 * key_recs + 4.0 * hf
+        achieved = bytes_per_query * a.queries / (kern_ms * 1e-3) / 1e9
+        out["roofline"].update({"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_query": bytes_per_query})
+        out["config"].update({"mphf_records_read_per_query": mphf_recs, "key_records_read_per_query": key_recs,
+                              "completed_evaluations_per_query": completed, "records_read_per_query": lines_per_query})
+        out["config"]["early_exit"] = not a.no_early_exit and not a.no_fingerprint
         if not a.no_gather_probe:
             # the north_star's own denominator: the measured random-read rate of this GPU (64 B per access)
-            lines_per_query = 3.0 * probes + checker_reads          # 3 MPHF records per probe + key records actually read
             peak_acc = gather_roofline(dev)
             ach_acc = lines_per_query * a.queries / (kern_ms * 1e-3)
             out["roofline"]["random_read"] = {"peak_accesses_per_s": peak_acc, "achieved_accesses_per_s": ach_acc, "frac": ach_acc / peak_acc,

@@ -87,6 +87,8 @@ int aix_index_info(const aix_index_t* h, aix_info_t* info);
 int aix_index_set_canonical_fastpath(aix_index_t* h, int enabled);
 /* switch the 4-bit fingerprint filter of the MPHF records off/on (A/B measurements; answers are identical) */
 int aix_index_set_fingerprint_filter(aix_index_t* h, int enabled);
+/* switch the early-exit MPHF walk (presence masks: an absent key usually costs one record read) off/on */
+int aix_index_set_early_exit(aix_index_t* h, int enabled);
 /* replace the tf table of a 13-mer handle (u64[4^13], mphf order, HOST pointer) */
 int aix_index_set_tf_13(aix_index_t* h, const uint64_t* tf);
 /* copy tf out (HOST pointer): 23 -> u32[n]; 13 -> u64[4^13] in mphf order
@@ -128,6 +130,8 @@ int aix_tf_batch_ragged(aix_index_t* h, const char* bytes, const uint64_t* offse
 int aix_tf_batch_ragged_dev(aix_index_t* h, const char* d_bytes, const uint64_t* d_offsets, uint64_t N,
                             uint32_t* d_out, void* stream);
 
+/* instrumentation for the roofline accounting: d_out[i] = MPHF + key records that tf query i reads (23-mer handles) */
+int aix_lines_batch_ascii_dev(aix_index_t* h, const char* d_kmers, uint64_t N, uint32_t* d_out, void* stream);
 /* get_hash_values / get_hash_value (python_wrapper.cpp:629-642): raw mphf::lookup of the bytes */
 int aix_hash_batch_ascii(aix_index_t* h, const char* kmers, uint64_t N, uint64_t* out);
 int aix_hash_batch_ascii_dev(aix_index_t* h, const char* d_kmers, uint64_t N, uint64_t* d_out, void* stream);

@@ -749,3 +749,29 @@ def test_count13_skewed_and_crlf_inputs(ix13):
     assert np.array_equal(ix13.count13(fq), O.count13(m, fq, -1))      # '\r' stays in the sequence line -> breaks windows
     fa = b"".join(b">s%d\r\n" % i + ln[:75] + b"\r\n" + ln[75:] + b"\r\n" for i, ln in enumerate(lines[:500]))
     assert np.array_equal(ix13.count13(fa), O.count13(m, fa, -1))
+
+
+def test_early_exit_walk_on_off(canon_case, ix23, q23):
+    """Presence-mask early exit: identical answers in every combination of the three switches, on the canonical
+    synthetic index and on the reference-built (non-canonical) golden index."""
+    ix, orc = canon_case["ix"], canon_case["orc"]
+    q = mixed_queries(canon_case["genome"], 300_000, 33)
+    want = orc.tf_batch(q, threads=8)
+    for fast in (True, False):
+        for fp in (True, False):
+            for ee in (True, False):
+                ix.set_canonical_fastpath(fast); ix.set_fingerprint_filter(fp); ix.set_early_exit(ee)
+                assert np.array_equal(ix.tf_ascii(q), want), (fast, fp, ee)
+    ix.set_canonical_fastpath(True); ix.set_fingerprint_filter(True); ix.set_early_exit(True)
+    kid, strand = ix.kid_strand_ascii(q[:5000])
+    assert strand.tolist() == [orc.strand(bytes(s)) for s in q[:5000]]
+    qs = flat(q23["queries"])
+    for ee in (True, False):
+        ix23.set_early_exit(ee)
+        assert ix23.tf_ascii(qs).tolist() == q23["tf"]
+        assert ix23.total_ascii(qs).tolist() == q23["total"]
+    ix23.set_early_exit(True)
+    import torch
+    from aindex_amd import engine
+    li = ix.lines_ascii_t(engine.synth_kmers_t(7, 200_000, 23)).cpu().numpy()
+    assert 1.0 <= float((li & 15).mean()) < 2.0          # absent keys stop after ~1.35 records on average
