@@ -101,3 +101,19 @@ def test_normalize_kmer_counter_rules(gold):
     lines = out[: n.value].tobytes().split(b"\n")
     assert lines[-1] == b"" and all(b">" not in ln and b"\r" not in ln for ln in lines)
     assert len(lines) - 1 == buf.count(b">")
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/aindex_hip.h compiles as C11 and every declared function resolves against libaindex_hip.so."""
+    import subprocess
+    src = tmp_path / "abi_check.c"
+    calls = "\n".join(f"    p[{i}] = (void*){name};" for i, name in enumerate(_lib.header_symbols()))
+    src.write_text('#include "aindex_hip.h"\n#include <stdio.h>\nint main(void) {\n    void* p[%d];\n%s\n'
+                   '    int n = 0; int st = aix_device_count(&n);\n    printf("%%s %%d %%d\\n", aix_version(), st, (int)(sizeof(p) / sizeof(p[0])));\n    return 0;\n}\n'
+                   % (len(_lib.header_symbols()), calls))
+    exe = tmp_path / "abi_check"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-Wno-pedantic", f"-I{os.path.join(_lib.ROOT, 'include')}", str(src), "-o", str(exe),
+                           f"-L{libdir}", "-laindex_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], stdout=subprocess.PIPE, timeout=120).stdout.decode()
+    assert "gfx950" in out
