@@ -55,6 +55,7 @@ struct aix_index {
     uint64_t mphf_n = 0, D = 0, seed = 0, B = 0, W = 0;
     // HBM
     BvRec* recs = nullptr;
+    EeRec* ee = nullptr;                       // early-exit table (23-mer handles with keys)
     KeyRec* keys = nullptr;
     uint64_t* tf13_mphf = nullptr;
     uint64_t* tf13_code = nullptr;
@@ -73,6 +74,7 @@ struct aix_index {
     IndexDev dev() const {
         IndexDev d{};
         d.m.recs = recs;
+        d.m.ee = ee;
         d.m.D = D;
         d.m.seed = seed;
         d.m.nrecs = (B + 15) / 16;
@@ -84,7 +86,7 @@ struct aix_index {
         d.canonical_only = (canonical_only && canonical_fastpath) ? 1u : 0u;
         d.k = k;
         d.use_fp = (has_fp && fp_filter) ? 1u : 0u;
-        d.early_exit = (has_fp && fp_filter && early_exit) ? 1u : 0u;
+        d.early_exit = (has_fp && ee && early_exit) ? 1u : 0u;
         return d;
     }
 };
@@ -169,7 +171,6 @@ static int upload_mphf(aix_index* h, const uint8_t* pf, uint64_t len) {
         recs[i].pairs = half;
         recs[i].prefix = (uint32_t)run;
         recs[i].fp = 0;
-        recs[i].present[0] = recs[i].present[1] = recs[i].present[2] = recs[i].present[3] = 0;
         run += (uint32_t)__builtin_popcount((half | (half >> 1)) & 0x55555555u);
     }
     if (run >> 32) return AIX_ERR_UNSUPPORTED;
@@ -192,6 +193,7 @@ static void destroy(aix_index* h) {
     if (!h) return;
     DevGuard g(h->device);
     if (h->recs) (void)hipFree(h->recs);
+    if (h->ee) (void)hipFree(h->ee);
     if (h->keys) (void)hipFree(h->keys);
     if (h->tf13_mphf) (void)hipFree(h->tf13_mphf);
     if (h->tf13_code) (void)hipFree(h->tf13_code);
@@ -216,7 +218,10 @@ static int adopt_device_arrays(aix_index* h, const uint64_t* d_checker, const ui
     (void)hipFree(d_flag);
     HIPCHK(e);
     h->canonical_only = (flag == 0);
-    HIPCHK(launch_set_fingerprints(h->dev().m, h->recs, h->keys, n, s));
+    const uint64_t nrec = (h->B + 15) / 16;
+    HIPCHK(hipMalloc((void**)&h->ee, sizeof(EeRec) * (nrec ? nrec : 1)));
+    h->device_bytes += sizeof(EeRec) * nrec;
+    HIPCHK(launch_set_fingerprints(h->dev().m, h->recs, h->ee, h->keys, n, s));
     HIPCHK(hipStreamSynchronize(s));
     h->has_fp = true;
     return AIX_OK;

@@ -26,21 +26,19 @@ namespace aix {
 // fp nibble j = fingerprint of the key whose assigned (hidx-selected) node is pair j (0 if none): a probe whose
 // fingerprint differs from the stored one cannot match checker[rank] and is answered "absent" without touching
 // the key table (15/16 of all misses).
-//
-// Second half of the record: an 8-bit presence mask per pair position. Every key sets one bit (chosen by hash bits
-// that are independent of the node index) in the mask of EACH of its three nodes, so a query that finds its bit
-// clear at any of its nodes is certainly not a stored key and the evaluation stops there: most absent keys cost ONE
-// line (first node) instead of three ("early-exit" MWHC evaluation; exactness argument in DESIGN.md §3).
-struct __attribute__((aligned(16))) BvHead {
+struct __attribute__((aligned(16))) BvRec {
     uint32_t pairs;      // 16 x 2 bits
     uint32_t prefix;
     uint64_t fp;         // 16 x 4 bits
 };
-struct __attribute__((aligned(32))) BvRec {
+// Early-exit table (23-mer lookups): the same pairs / prefix plus a 12-bit presence mask per pair position.
+// Every key sets TWO bits (chosen by hash bits that do not depend on the node index) in the mask of EACH of its three
+// nodes, so a query that finds one of its bits clear at any of its nodes is certainly not a stored key and the walk
+// stops there: most absent keys cost ONE line (first node) instead of three (exactness argument: DESIGN.md §3).
+struct __attribute__((aligned(32))) EeRec {
     uint32_t pairs;
     uint32_t prefix;
-    uint64_t fp;
-    uint32_t present[4]; // 16 x 8 bits
+    uint32_t mask[6];    // 16 x 12 bits, field j at bit 12 j
 };
 // checker[] and tf[] of PHASH_MAP (hash.hpp:82-121) interleaved: one 16-byte read per probe.
 struct __attribute__((aligned(16))) KeyRec {
@@ -300,6 +298,7 @@ __device__ __forceinline__ void load13(const uint8_t* p, uint64_t& w0, uint64_t&
 // MPHF evaluation against the device layout
 // ---------------------------------------------------------------------------------------------
 struct MphfDev {
+    const EeRec* ee;     // early-exit table (nullptr when not built)
     const BvRec* recs;   // W records
     uint64_t D;          // hash domain
     uint64_t seed;
@@ -315,9 +314,9 @@ __device__ __forceinline__ uint64_t mphf_from_hash_fp(const MphfDev& m, uint64_t
     const uint64_t n0 = fastmod(a, m.fm);
     const uint64_t n1 = m.D + fastmod(b, m.fm);
     const uint64_t n2 = 2 * m.D + fastmod(c, m.fm);
-    const BvHead r0 = *(const BvHead*)(m.recs + (n0 >> 4));      // first 16 bytes of the 32-byte record
-    const BvHead r1 = *(const BvHead*)(m.recs + (n1 >> 4));
-    const BvHead r2 = *(const BvHead*)(m.recs + (n2 >> 4));
+    const BvRec r0 = m.recs[n0 >> 4];
+    const BvRec r1 = m.recs[n1 >> 4];
+    const BvRec r2 = m.recs[n2 >> 4];
     const uint32_t s0 = (uint32_t)(n0 & 15) * 2, s1 = (uint32_t)(n1 & 15) * 2, s2 = (uint32_t)(n2 & 15) * 2;
     const uint32_t v = ((r0.pairs >> s0) & 3) + ((r1.pairs >> s1) & 3) + ((r2.pairs >> s2) & 3);
     const uint32_t hidx = v - 3u * ((v * 11u) >> 5);               // v in 0..9 -> v % 3
@@ -331,40 +330,48 @@ __device__ __forceinline__ uint64_t mphf_from_hash_fp(const MphfDev& m, uint64_t
     return (uint64_t)p + (uint32_t)__builtin_popcount((below | (below >> 1)) & 0x55555555u);
 }
 
-// which presence bit a key sets at its i-th node (i = 0, 1, 2)
-__device__ __forceinline__ uint32_t present_bit(uint64_t a, uint64_t b, uint64_t c, int i) { return (uint32_t)((a ^ b ^ c) >> (57 - 3 * i)) & 7u; }
-// the presence dword of a node is read straight from memory (a register copy of the whole record would be indexed at
-// run time and spilled to scratch); it sits in the same 32-byte record, i.e. the same line, as the head
-__device__ __forceinline__ bool present_at(const BvRec* recs, uint64_t node, uint32_t bit) {
-    const uint32_t j = (uint32_t)(node & 15);
-    const uint32_t w = recs[node >> 4].present[j >> 2];
-    return ((w >> (8 * (j & 3) + bit)) & 1u) != 0;
+// the two presence bits (of 12) a key sets at its i-th node (i = 0, 1, 2): 8 hash bits each, multiply-shift into 0..11
+__device__ __forceinline__ uint32_t present_mask(uint64_t a, uint64_t b, uint64_t c, int i) {
+    const uint64_t x = a ^ b ^ c;
+    const uint32_t g1 = (uint32_t)(((x >> (56 - 16 * i)) & 0xFFu) * 12u) >> 8;
+    const uint32_t g2 = (uint32_t)(((x >> (48 - 16 * i)) & 0xFFu) * 12u) >> 8;
+    return (1u << g1) | (1u << g2);
+}
+// 12-bit presence field of a node, read straight from memory (same 32-byte record, i.e. same line, as pairs/prefix;
+// a register copy of the whole record would be indexed at run time and spilled to scratch)
+__device__ __forceinline__ uint32_t present_field(const EeRec* ee, uint64_t node) {
+    const uint32_t bit = (uint32_t)(node & 15) * 12u;
+    const uint32_t* w = ee[node >> 4].mask + (bit >> 5);
+    const uint32_t sh = bit & 31u;
+    uint32_t v = w[0] >> sh;
+    if (sh > 20u) v |= w[1] << (32u - sh);                          // field straddles two dwords (never the last one)
+    return v & 0xFFFu;
 }
 
 // Early-exit evaluation: the three records are read one after the other and the walk stops at the first node whose
-// presence mask lacks the key's bit. Returns false ("certainly not a stored key") or true with slot / fingerprint.
-__device__ __forceinline__ bool mphf_probe_early_exit(const MphfDev& m, uint64_t a, uint64_t b, uint64_t c, uint64_t& slot, uint32_t& fp_stored,
-                                                      uint32_t& records_read) {
+// presence field lacks one of the key's bits. Returns false ("certainly not a stored key") or true with the slot.
+__device__ __forceinline__ bool mphf_probe_early_exit(const MphfDev& m, uint64_t a, uint64_t b, uint64_t c, uint64_t& slot, uint32_t& records_read) {
     const uint64_t n0 = fastmod(a, m.fm);
-    const BvHead r0 = *(const BvHead*)(m.recs + (n0 >> 4));
+    const uint2 h0 = *(const uint2*)(m.ee + (n0 >> 4));             // {pairs, prefix}
+    const uint32_t q0 = present_mask(a, b, c, 0);
     records_read = 1;
-    if (!present_at(m.recs, n0, present_bit(a, b, c, 0))) return false;
+    if ((present_field(m.ee, n0) & q0) != q0) return false;
     const uint64_t n1 = m.D + fastmod(b, m.fm);
-    const BvHead r1 = *(const BvHead*)(m.recs + (n1 >> 4));
+    const uint2 h1 = *(const uint2*)(m.ee + (n1 >> 4));
+    const uint32_t q1 = present_mask(a, b, c, 1);
     records_read = 2;
-    if (!present_at(m.recs, n1, present_bit(a, b, c, 1))) return false;
+    if ((present_field(m.ee, n1) & q1) != q1) return false;
     const uint64_t n2 = 2 * m.D + fastmod(c, m.fm);
-    const BvHead r2 = *(const BvHead*)(m.recs + (n2 >> 4));
+    const uint2 h2 = *(const uint2*)(m.ee + (n2 >> 4));
+    const uint32_t q2 = present_mask(a, b, c, 2);
     records_read = 3;
-    if (!present_at(m.recs, n2, present_bit(a, b, c, 2))) return false;
+    if ((present_field(m.ee, n2) & q2) != q2) return false;
     const uint32_t s0 = (uint32_t)(n0 & 15) * 2, s1 = (uint32_t)(n1 & 15) * 2, s2 = (uint32_t)(n2 & 15) * 2;
-    const uint32_t v = ((r0.pairs >> s0) & 3) + ((r1.pairs >> s1) & 3) + ((r2.pairs >> s2) & 3);
+    const uint32_t v = ((h0.x >> s0) & 3) + ((h1.x >> s1) & 3) + ((h2.x >> s2) & 3);
     const uint32_t hidx = v - 3u * ((v * 11u) >> 5);
-    const uint32_t w = hidx == 0 ? r0.pairs : (hidx == 1 ? r1.pairs : r2.pairs);
-    const uint32_t p = hidx == 0 ? r0.prefix : (hidx == 1 ? r1.prefix : r2.prefix);
+    const uint32_t w = hidx == 0 ? h0.x : (hidx == 1 ? h1.x : h2.x);
+    const uint32_t p = hidx == 0 ? h0.y : (hidx == 1 ? h1.y : h2.y);
     const uint32_t sh = hidx == 0 ? s0 : (hidx == 1 ? s1 : s2);
-    const uint64_t f = hidx == 0 ? r0.fp : (hidx == 1 ? r1.fp : r2.fp);
-    fp_stored = (uint32_t)(f >> (sh * 2)) & 15u;
     const uint32_t below = w & ((1u << sh) - 1u);
     slot = (uint64_t)p + (uint32_t)__builtin_popcount((below | (below >> 1)) & 0x55555555u);
     return true;

@@ -40,7 +40,7 @@ hipError_t launch_coverage(const IndexDev& ix, const uint8_t* seqs, const uint64
 
 // index construction helpers
 hipError_t launch_build_keyrecs(const uint64_t* checker, const uint32_t* tf, uint64_t n, KeyRec* recs, uint32_t* noncanon_count, hipStream_t s);
-hipError_t launch_set_fingerprints(const MphfDev& m, BvRec* recs_rw, const KeyRec* keys, uint64_t n, hipStream_t s);
+hipError_t launch_set_fingerprints(const MphfDev& m, BvRec* recs_rw, EeRec* ee_rw, const KeyRec* keys, uint64_t n, hipStream_t s);
 hipError_t launch_scatter23(const MphfDev& m, uint64_t n, const uint8_t* keys_ascii /* or */, const uint64_t* codes, const uint32_t* counts,
                             uint64_t* checker, uint32_t* tf, uint32_t* occupied_bits, uint32_t* conflict, hipStream_t s);
 hipError_t launch_perm13(const MphfDev& m, uint32_t* perm /* [4^13]: code -> mphf index */, hipStream_t s);

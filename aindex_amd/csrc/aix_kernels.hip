@@ -36,10 +36,8 @@ __device__ __forceinline__ Probe probe23(const IndexDev& ix, uint64_t w0, uint64
     r.slot = 0;
     r.lines = 3;
     if (ix.early_exit) {
-        uint32_t fps;
-        if (!mphf_probe_early_exit(ix.m, a, b, c, r.slot, fps, r.lines)) return r;   // a node lacks the key's presence bit
+        if (!mphf_probe_early_exit(ix.m, a, b, c, r.slot, r.lines)) return r;   // a node lacks one of the key's presence bits
         r.lines += 256;
-        if (fps != fp_of_hash(a, b, c)) return r;
     } else if (ix.use_fp) {
         r.lines += 256;
         uint32_t fps;
@@ -352,7 +350,18 @@ __global__ void __launch_bounds__(kBlock) k_extract(const KeyRec* __restrict__ r
 // Fingerprints: for every stored code that sits in its own MPHF slot, write its 4-bit fingerprint into the nibble
 // of its assigned node. Entries that are not where the MPHF puts them (corrupt / foreign index) are skipped, so a
 // fingerprint mismatch always implies checker[rank] != query.
-__global__ void __launch_bounds__(kBlock) k_set_fp(const MphfDev m, BvRec* __restrict__ recs, const KeyRec* __restrict__ keys, uint64_t n) {
+__global__ void __launch_bounds__(kBlock) k_init_ee(const BvRec* __restrict__ recs, uint64_t nrecs, EeRec* __restrict__ ee) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < nrecs; i += stride) {
+        EeRec e;
+        e.pairs = recs[i].pairs;
+        e.prefix = recs[i].prefix;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) e.mask[k] = 0;
+        ee[i] = e;
+    }
+}
+__global__ void __launch_bounds__(kBlock) k_set_fp(const MphfDev m, BvRec* __restrict__ recs, EeRec* __restrict__ ee, const KeyRec* __restrict__ keys, uint64_t n) {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         const uint64_t code = keys[i].code;
@@ -365,9 +374,12 @@ __global__ void __launch_bounds__(kBlock) k_set_fp(const MphfDev m, BvRec* __res
         atomicOr((unsigned long long*)&recs[node >> 4].fp, (unsigned long long)fp_of_hash(a, b, c) << (4 * (uint32_t)(node & 15)));
         const uint64_t nd[3] = {fastmod(a, m.fm), m.D + fastmod(b, m.fm), 2 * m.D + fastmod(c, m.fm)};
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {                     // presence bit of this key at each of its three nodes
-            const uint32_t j = (uint32_t)(nd[t] & 15);
-            atomicOr(&recs[nd[t] >> 4].present[j >> 2], 1u << (8 * (j & 3) + present_bit(a, b, c, t)));
+        for (int t = 0; t < 3; ++t) {                     // the key's two presence bits at each of its three nodes
+            const uint32_t bit = (uint32_t)(nd[t] & 15) * 12u, sh = bit & 31u;
+            const uint32_t q = present_mask(a, b, c, t);
+            uint32_t* w = ee[nd[t] >> 4].mask + (bit >> 5);
+            atomicOr(w, q << sh);
+            if (sh > 20u) atomicOr(w + 1, q >> (32u - sh));
         }
     }
 }
@@ -606,7 +618,7 @@ __global__ void __launch_bounds__(kBlock) k_gather(const uint8_t* __restrict__ t
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             if (ELEM == 16) {
-                const BvHead r = ((const BvHead*)table)[idx[u]];
+                const BvRec r = ((const BvRec*)table)[idx[u]];
                 acc += r.fp ^ r.prefix;
             } else if (ELEM == 8) {
                 acc += ((const uint64_t*)table)[idx[u]];
@@ -679,9 +691,10 @@ hipError_t launch_extract_tf(const KeyRec* recs, uint64_t n, uint32_t* tf, uint6
     if (n == 0) return hipSuccess;
     AIX_LAUNCH(k_extract, n, s, recs, n, tf, checker);
 }
-hipError_t launch_set_fingerprints(const MphfDev& m, BvRec* recs_rw, const KeyRec* keys, uint64_t n, hipStream_t s) {
+hipError_t launch_set_fingerprints(const MphfDev& m, BvRec* recs_rw, EeRec* ee_rw, const KeyRec* keys, uint64_t n, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    AIX_LAUNCH(k_set_fp, n, s, m, recs_rw, keys, n);
+    hipLaunchKernelGGL(k_init_ee, dim3(grid_for(m.nrecs)), dim3(kBlock), 0, s, (const BvRec*)recs_rw, m.nrecs, ee_rw);
+    AIX_LAUNCH(k_set_fp, n, s, m, recs_rw, ee_rw, keys, n);
 }
 hipError_t launch_scatter23(const MphfDev& m, uint64_t n, const uint8_t* keys, const uint64_t* codes, const uint32_t* counts, uint64_t* checker, uint32_t* tf,
                             uint32_t* occupied, uint32_t* conflict, hipStream_t s) {

@@ -365,7 +365,7 @@ def main():
                                                                    "note": "what the reference's two-probe evaluation would have read for these queries"}})
         out["config"].update({"mphf_records_read_per_query": mphf_recs, "key_records_read_per_query": key_recs,
                               "completed_evaluations_per_query": completed, "records_read_per_query": lines_per_query})
-        out["config"]["early_exit"] = not a.no_early_exit and not a.no_fingerprint
+        out["config"]["early_exit"] = not a.no_early_exit
         if not a.no_gather_probe:
             # the north_star's own denominator: the measured random-read rate of this GPU (64 B per access)
             peak_acc = gather_roofline(dev)
