@@ -27,7 +27,11 @@ struct Probe {
     bool found;
 };
 // hash the 23 ASCII bytes in (w0,w1,w2), evaluate the MPHF, verify against the stored code
-__device__ __forceinline__ Probe probe23(const IndexDev& ix, uint64_t w0, uint64_t w1, uint64_t w2, uint64_t code) {
+// `filters`: the hashed bytes are exactly the ASCII of `code`. Only then do a stored key's fingerprint / presence
+// bits (computed from ITS ASCII) say anything about this probe; the reference's forward probe of a query with
+// non-ACGT bytes hashes the raw bytes but compares the sanitised code (python_wrapper.cpp:611-613) and can — by a
+// 1-in-n coincidence of slots — match a stored key whose hash is different, so that probe runs unfiltered.
+__device__ __forceinline__ Probe probe23(const IndexDev& ix, uint64_t w0, uint64_t w1, uint64_t w2, uint64_t code, bool filters = true) {
     uint64_t a, b, c;
     jenkins23(w0, w1, w2, ix.m.seed, a, b, c);
     Probe r;
@@ -35,7 +39,10 @@ __device__ __forceinline__ Probe probe23(const IndexDev& ix, uint64_t w0, uint64
     r.tf = 0;
     r.slot = 0;
     r.lines = 3;
-    if (ix.early_exit) {
+    if (!filters) {
+        r.lines += 256;
+        r.slot = mphf_from_hash(ix.m, a, b, c);
+    } else if (ix.early_exit) {
         if (!mphf_probe_early_exit(ix.m, a, b, c, r.slot, r.lines)) return r;   // a node lacks one of the key's presence bits
         r.lines += 256;
     } else if (ix.use_fp) {
@@ -98,7 +105,7 @@ __device__ __forceinline__ Q23 query23(const IndexDev& ix, uint64_t w0, uint64_t
         }
         return out;
     }
-    const Probe f = probe23(ix, w0, w1, w2, e.code);           // raw bytes hashed, sanitised code compared
+    const Probe f = probe23(ix, w0, w1, w2, e.code, e.valid);  // raw bytes hashed, sanitised code compared
     out.lines = f.lines;
     if (f.found) { out.slot = f.slot; out.tf = f.tf; out.strand = 1; return out; }
     uint64_t r0, r1, r2;
@@ -121,7 +128,7 @@ __device__ __forceinline__ void both23(const IndexDev& ix, uint64_t w0, uint64_t
     }
     uint64_t r0, r1, r2;
     ascii23_of_rc(e.code, r0, r1, r2);
-    const Probe F = probe23(ix, w0, w1, w2, e.code);
+    const Probe F = probe23(ix, w0, w1, w2, e.code, e.valid);
     const Probe R = probe23(ix, r0, r1, r2, r);
     Probe S = F;
     if (!e.valid) {                                             // second call's fallback decodes the sanitised code

@@ -1,0 +1,85 @@
+"""Differential fuzzing: many small random indexes / query sets / read buffers, HIP path vs the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle_lib as O
+from aindex_amd import _lib, builder, synth
+from aindex_amd.engine import Index
+
+ALPH = np.frombuffer(b"ACGTACGTACGTNacgtn~\n?U", dtype=np.uint8)
+
+
+def make_case(seed, tmp):
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([1, 3, 4, 7, 50, 333, 2000, 6000]))
+    codes = np.unique(rng.integers(0, 4 ** 23, size=n, dtype=np.uint64))
+    mode = seed % 3
+    if mode == 0:                                  # all true-canonical -> fast path
+        codes = np.unique(np.minimum(codes, synth.revcomp_codes(codes, 23)))
+    elif mode == 1:                                # both strands of some keys stored
+        codes = np.unique(np.concatenate([codes, synth.revcomp_codes(codes[: max(1, len(codes) // 3)], 23)]))
+    if codes.shape[0] == 2:                        # hash domain 1 is never peelable (also in the reference)
+        codes = codes[:1]
+    tfs = rng.integers(0, 1000, size=codes.shape[0]).astype(np.uint32)
+    tfs[rng.integers(0, codes.shape[0])] = 0xFFFFFFFF
+    pf = builder.build_pf_codes(codes, 23)
+    prefix = os.path.join(tmp, f"f{seed}")
+    open(prefix + ".pf", "wb").write(pf)
+    m = O.OracleMphf(prefix + ".pf")
+    keys = synth.decode_kmers(codes, 23)
+    rc, checker, tf = O.index_scatter(m, np.ascontiguousarray(keys).reshape(-1), tfs)
+    assert rc == 0
+    checker.tofile(prefix + ".kmers.bin")
+    tf.tofile(prefix + ".tf.bin")
+    return rng, codes, keys, prefix
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_queries_counts_positions(seed, tmp_path):
+    rng, codes, keys, prefix = make_case(seed, str(tmp_path))
+    orc = O.OracleIndex23.from_prefix(prefix)
+    with Index.open_23(prefix + ".pf", prefix + ".tf.bin", prefix + ".kmers.bin") as ix:
+        assert ix.canonical_only == bool(np.all(codes <= synth.revcomp_codes(codes, 23)))
+        nq = 3000
+        q = ALPH[rng.integers(0, ALPH.shape[0], size=(nq, 23))].copy()
+        pick = rng.integers(0, keys.shape[0], size=nq // 3)
+        q[: nq // 3] = keys[pick]
+        q[nq // 3: nq // 2] = synth.decode_kmers(synth.revcomp_codes(codes[pick[: nq // 2 - nq // 3]], 23), 23)
+        mut = rng.integers(0, nq // 2, size=200)
+        q[mut, rng.integers(0, 23, size=200)] = ALPH[rng.integers(0, ALPH.shape[0], size=200)]
+        want_tf = orc.tf_batch(q)
+        qb = [bytes(x) for x in q[:400]]
+        for fast in (True, False):
+            for ee in (True, False):
+                ix.set_canonical_fastpath(fast); ix.set_early_exit(ee)
+                assert np.array_equal(ix.tf_ascii(q), want_tf), (seed, fast, ee)
+        ix.set_canonical_fastpath(True); ix.set_early_exit(True)
+        assert ix.total_ascii(q[:400]).tolist() == [orc.total(b) for b in qb]
+        f, r = ix.both_ascii(q[:400])
+        assert [(int(a), int(b)) for a, b in zip(f, r)] == [orc.both(b) for b in qb]
+        kid, strand = ix.kid_strand_ascii(q[:400])
+        assert strand.tolist() == [orc.strand(b) for b in qb] and kid.tolist() == [orc.kid(b) for b in qb]
+        assert np.array_equal(ix.hash_ascii(q[:400]), orc.hash_batch(q[:400]))
+        # ragged lengths
+        items = [bytes(x)[: int(rng.integers(0, 24))] + bytes(ALPH[rng.integers(0, 8, size=int(rng.integers(0, 30)))]) for x in q[:300]]
+        assert ix.tf_ragged(items).tolist() == [orc.tf(b) for b in items]
+        # a reads-like buffer built from keys, their reverse complements and noise, with separators
+        parts = []
+        for i in range(60):
+            k1 = bytes(keys[int(rng.integers(0, keys.shape[0]))])
+            noise = bytes(ALPH[rng.integers(0, ALPH.shape[0], size=int(rng.integers(0, 40)))])
+            parts.append(k1 + noise + bytes(q[int(rng.integers(0, nq))]) + (b"\n" if i % 3 else b"~"))
+        buf = b"".join(parts)
+        for mode in (0, 1, 2):
+            assert np.array_equal(ix.count23_fixed(buf, _lib.FMT_PLAIN, mode), orc.count23_fixed(buf, False, mode)), (seed, mode)
+        ind, pos = ix.positions_fill(buf)
+        oind, opos = orc.positions(buf)
+        assert np.array_equal(ind, oind) and np.array_equal(pos, opos)
+        seqs = [buf[:200], buf[200:460], b"", buf[-30:]]
+        for cutoff in (0, 5):
+            for s, got in zip(seqs, ix.coverage(seqs, cutoff)):
+                assert np.array_equal(got, orc.coverage(s, cutoff))
