@@ -83,3 +83,83 @@ def test_fuzz_queries_counts_positions(seed, tmp_path):
         for cutoff in (0, 5):
             for s, got in zip(seqs, ix.coverage(seqs, cutoff)):
                 assert np.array_equal(got, orc.coverage(s, cutoff))
+
+
+# ------------------------------------------------------------------------------------------------
+# 13-mer mode: random buffers in the three input formats, then noisy queries against the counted table
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def ix13():
+    from pf13 import pf13_path
+    ix = Index.open_13(pf13_path(), None)
+    yield ix
+    ix.close()
+
+
+def _rand_seq(rng, lo, hi):
+    return bytes(ALPH[rng.integers(0, ALPH.shape[0] - 3, size=int(rng.integers(lo, hi)))])     # no '~', '\n', '?' inside
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_13mer(seed, ix13):
+    from pf13 import pf13_path
+    rng = np.random.default_rng(1000 + seed)
+    m = O.OracleMphf(pf13_path())
+    kind = seed % 4
+    recs = [_rand_seq(rng, 0, 120) for _ in range(int(rng.integers(1, 60)))]
+    if kind == 0:
+        buf = b"".join(r + (b"\n" if rng.random() < 0.9 else b"~" + _rand_seq(rng, 0, 50) + b"\n") for r in recs)
+    elif kind == 1:
+        buf = b"".join(b">h%d %s\n" % (i, _rand_seq(rng, 0, 10)) + b"".join(r[j:j + 37] + (b"\r\n" if i % 7 == 0 else b"\n") for j in range(0, len(r), 37)) +
+                       (b"\n" if i % 5 == 0 else b"") for i, r in enumerate(recs))
+    elif kind == 2:
+        buf = b"".join(b"@r%d\n" % i + r + b"\n+\n" + b"I" * len(r) + b"\n" for i, r in enumerate(recs))
+    else:
+        buf = b"\n" + b"".join(r + b"\n" for r in recs)                    # empty first line -> PLAIN
+    if seed >= 4:
+        buf = buf.rstrip(b"\n")                                            # no trailing newline
+    want = O.count13(m, buf, -1)
+    got = ix13.count13(buf)
+    assert np.array_equal(got, want), (seed, kind)
+    tf = want.copy()
+    tf[np.nonzero(tf)[0][::3]] += np.uint64(1 << 33)                       # > 32-bit values
+    ix13.set_tf_13(tf)
+    orc = O.OracleIndex13(pf13_path(), tf)
+    plain = [r for r in recs if len(r) >= 13]
+    q = []
+    for r in plain[:40]:
+        p = int(rng.integers(0, len(r) - 12))
+        q.append(r[p:p + 13])
+    q += [bytes(ALPH[rng.integers(0, ALPH.shape[0], size=13)]) for _ in range(200)]
+    q += [bytes(ALPH[rng.integers(0, 12, size=13)]) for _ in range(200)]   # mostly valid upper-case
+    qa = np.frombuffer(b"".join(q), dtype=np.uint8)
+    assert np.array_equal(ix13.tf_ascii(qa), orc.tf_batch(qa))
+    assert ix13.total_ascii(qa).tolist() == [orc.total(s) for s in q]
+    f, r2 = ix13.both_ascii(qa)
+    assert [(int(a), int(b)) for a, b in zip(f, r2)] == [orc.both(s) for s in q]
+    items = [s[: int(rng.integers(0, 14))] + bytes(ALPH[rng.integers(0, 8, size=int(rng.integers(0, 5)))]) for s in q[:100]]
+    assert ix13.tf_ragged(items).tolist() == [orc.tf(s) for s in items]
+    for s, got_cov in zip(plain[:5], ix13.coverage(plain[:5], 1)):
+        assert np.array_equal(got_cov, orc.coverage(s, 1))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_normalise_and_distinct(seed):
+    """Random FASTA/FASTQ-like byte soup: device normalisation == host normalisation; distinct k-mer sets == oracle."""
+    import torch
+    from aindex_amd import counting
+    rng = np.random.default_rng(2000 + seed)
+    soup = np.frombuffer(b"ACGTACGTACGTNacgtu>@+\n\n\r ~U", dtype=np.uint8)
+    buf = bytes(soup[rng.integers(0, soup.shape[0], size=int(rng.integers(1, 40000)))])
+    if seed % 2 == 0:
+        buf = b">" + buf
+    t = torch.frombuffer(bytearray(buf), dtype=torch.uint8).cuda()
+    for fmt, mode in ((1, 0), (1, 1), (2, 0)):
+        want = counting.normalize(buf, fmt, mode)
+        got = counting.normalize_t(t, fmt, mode).cpu().numpy().tobytes()
+        assert got == want, (seed, fmt, mode)
+    for k in (5, 13, 17, 23, 31):
+        for canon in (0, 1, 2):
+            keys, counts = counting.count_distinct(buf, k, canon, 1 + seed % 2)
+            okeys, ocnt = O.count_distinct(buf, k, canon, 1 + seed % 2)
+            assert np.array_equal(keys, okeys) and np.array_equal(counts, ocnt), (seed, k, canon)
