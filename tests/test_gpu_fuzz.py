@@ -163,3 +163,62 @@ def test_fuzz_normalise_and_distinct(seed):
             keys, counts = counting.count_distinct(buf, k, canon, 1 + seed % 2)
             okeys, ocnt = O.count_distinct(buf, k, canon, 1 + seed % 2)
             assert np.array_equal(keys, okeys) and np.array_equal(counts, ocnt), (seed, k, canon)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_corrupt_index_files(seed, tmp_path):
+    """Index files that disagree with the MPHF (swapped / foreign / duplicated / out-of-range codes, short tf file,
+    extra trailing entries): the HIP path must answer exactly like the reference's evaluator on the same files."""
+    rng, codes, keys, prefix = make_case(100 + seed, str(tmp_path))
+    checker = np.fromfile(prefix + ".kmers.bin", dtype=np.uint64)
+    tf = np.fromfile(prefix + ".tf.bin", dtype=np.uint32)
+    n = checker.shape[0]
+    for _ in range(max(1, n // 10)):
+        i, j = rng.integers(0, n, size=2)
+        op = int(rng.integers(0, 5))
+        if op == 0:
+            checker[[i, j]] = checker[[j, i]]
+        elif op == 1:
+            checker[i] = rng.integers(0, 4 ** 23, dtype=np.uint64)
+        elif op == 2:
+            checker[i] = checker[j]
+        elif op == 3:
+            checker[i] |= np.uint64(1) << np.uint64(int(rng.integers(46, 64)))
+        else:
+            checker[i] = synth.revcomp_codes(checker[j:j + 1] & np.uint64(4 ** 23 - 1), 23)[0]
+    extra = int(rng.integers(0, 4))
+    if extra:
+        checker = np.concatenate([checker, rng.integers(0, 4 ** 23, size=extra, dtype=np.uint64)])
+        tf = np.concatenate([tf, rng.integers(1, 9, size=extra).astype(np.uint32)])
+    p2 = os.path.join(str(tmp_path), "c")
+    checker.tofile(p2 + ".kmers.bin")
+    tf[: max(0, tf.shape[0] - int(rng.integers(0, 3)))].tofile(p2 + ".tf.bin")          # tf file may be short (hash.cpp:431-444)
+    import shutil
+    shutil.copy(prefix + ".pf", p2 + ".pf")
+    orc = O.OracleIndex23.from_prefix(p2)
+    allc = np.unique(np.concatenate([codes, checker & np.uint64(4 ** 23 - 1)]))
+    q = np.concatenate([synth.decode_kmers(allc, 23), synth.decode_kmers(synth.revcomp_codes(allc, 23), 23),
+                        ALPH[rng.integers(0, ALPH.shape[0], size=(500, 23))]])
+    if q.shape[0] > 6000:
+        q = q[rng.permutation(q.shape[0])[:6000]]
+    q = q.copy()
+    mut = rng.integers(0, q.shape[0], size=300)
+    q[mut, rng.integers(0, 23, size=300)] = ALPH[rng.integers(0, ALPH.shape[0], size=300)]
+    want = orc.tf_batch(q)
+    qb = [bytes(x) for x in q[:300]]
+    with Index.open_23(p2 + ".pf", p2 + ".tf.bin", p2 + ".kmers.bin") as ix:
+        for fast in (True, False):
+            for fp in (True, False):
+                for ee in (True, False):
+                    ix.set_canonical_fastpath(fast); ix.set_fingerprint_filter(fp); ix.set_early_exit(ee)
+                    assert np.array_equal(ix.tf_ascii(q), want), (seed, fast, fp, ee)
+        ix.set_canonical_fastpath(True); ix.set_fingerprint_filter(True); ix.set_early_exit(True)
+        kid, strand = ix.kid_strand_ascii(q[:300])
+        assert strand.tolist() == [orc.strand(b) for b in qb] and kid.tolist() == [orc.kid(b) for b in qb]
+        assert ix.total_ascii(q[:300]).tolist() == [orc.total(b) for b in qb]
+        buf = b"\n".join(bytes(x) for x in q[:200]) + b"\n"
+        for mode in (0, 1, 2):
+            assert np.array_equal(ix.count23_fixed(buf, _lib.FMT_PLAIN, mode), orc.count23_fixed(buf, False, mode))
+        ind, pos = ix.positions_fill(buf)
+        oind, opos = orc.positions(buf)
+        assert np.array_equal(ind, oind) and np.array_equal(pos, opos)
