@@ -39,13 +39,12 @@ __device__ __forceinline__ uint32_t encode_run13(const uint8_t* __restrict__ buf
     }
     const uint64_t limit = len - S;                   // bytes available from S
     {
-        const uintptr_t a = (uintptr_t)(buf + S);
-        const uint32_t o = (uint32_t)(a & 3);
-        const uint32_t* q = (const uint32_t*)(a - o);
-        const uintptr_t endp = (uintptr_t)(buf + len);
+        const uint32_t o = (uint32_t)((uintptr_t)(buf + S) & 3);
+        const uint32_t* q = (const uint32_t*)(buf + S - o);           // pointer arithmetic keeps these global_load (not flat_load)
+        const int64_t first = (int64_t)S - o, end = (int64_t)len;     // byte offset of d[0] from buf (>= -3)
         uint32_t d[ND + 1];
 #pragma unroll
-        for (int k = 0; k <= ND; ++k) d[k] = ((uintptr_t)(q + k) < endp) ? q[k] : 0x0A0A0A0Au;   // never read a dword past the buffer
+        for (int k = 0; k <= ND; ++k) d[k] = (first + 4 * k < end) ? q[k] : 0x0A0A0A0Au;   // never read a dword past the buffer
         const uint32_t sh = o * 8;
 #pragma unroll
         for (int k = 0; k < ND; ++k) e[k] = __funnelshift_r(d[k], d[k + 1], sh);
@@ -207,13 +206,19 @@ __global__ void __launch_bounds__(C13_TB) k_c13_hist(const uint16_t* __restrict_
             for (unsigned long long i = lo + threadIdx.x; i < lo8; i += C13_TB) atomicAdd(&h[parts[i]], 1u);
             const uint4* v = (const uint4*)(parts + lo8);
             const unsigned long long nv = (hi8 - lo8) >> 3;
-            for (unsigned long long i = threadIdx.x; i < nv; i += C13_TB) {
-                const uint4 x = v[i];
+            auto add8 = [&](const uint4& x) {
                 atomicAdd(&h[x.x & 0xFFFFu], 1u); atomicAdd(&h[x.x >> 16], 1u);
                 atomicAdd(&h[x.y & 0xFFFFu], 1u); atomicAdd(&h[x.y >> 16], 1u);
                 atomicAdd(&h[x.z & 0xFFFFu], 1u); atomicAdd(&h[x.z >> 16], 1u);
                 atomicAdd(&h[x.w & 0xFFFFu], 1u); atomicAdd(&h[x.w >> 16], 1u);
+            };
+            // one workgroup per CU: four 16-byte loads per lane in flight (64 KiB per CU) to cover the HBM latency
+            unsigned long long i = threadIdx.x;
+            for (; i + 3 * C13_TB < nv; i += 4 * C13_TB) {
+                const uint4 x0 = v[i], x1 = v[i + C13_TB], x2 = v[i + 2 * C13_TB], x3 = v[i + 3 * C13_TB];
+                add8(x0); add8(x1); add8(x2); add8(x3);
             }
+            for (; i < nv; i += C13_TB) add8(v[i]);
             for (unsigned long long i = hi8 + threadIdx.x; i < hi; i += C13_TB) atomicAdd(&h[parts[i]], 1u);
         } else {
             for (unsigned long long i = lo + threadIdx.x; i < hi; i += C13_TB) atomicAdd(&h[parts[i]], 1u);

@@ -269,9 +269,8 @@ AIX_HD Enc13 encode13_words(uint64_t w0, uint64_t w1) {
 // window that lies inside the caller's buffer can never fault, whatever the buffer's alignment.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void load23(const uint8_t* p, uint64_t& w0, uint64_t& w1, uint64_t& w2) {
-    const uintptr_t a = (uintptr_t)p;
-    const uint32_t o = (uint32_t)(a & 3);
-    const uint32_t* q = (const uint32_t*)(a - o);
+    const uint32_t o = (uint32_t)((uintptr_t)p & 3);
+    const uint32_t* q = (const uint32_t*)(p - o);     // pointer arithmetic, not integer round trip: the loads stay global_load, not flat_load
     const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3], d4 = q[4], d5 = q[5];
     const uint32_t d6 = (o >= 2) ? q[6] : 0u;        // bytes 20..22 reach dword 6 only when o >= 2
     const uint32_t sh = o * 8;
@@ -283,9 +282,8 @@ __device__ __forceinline__ void load23(const uint8_t* p, uint64_t& w0, uint64_t&
     w2 = e4 | ((uint64_t)e5 << 32);
 }
 __device__ __forceinline__ void load13(const uint8_t* p, uint64_t& w0, uint64_t& w1) {
-    const uintptr_t a = (uintptr_t)p;
-    const uint32_t o = (uint32_t)(a & 3);
-    const uint32_t* q = (const uint32_t*)(a - o);
+    const uint32_t o = (uint32_t)((uintptr_t)p & 3);
+    const uint32_t* q = (const uint32_t*)(p - o);     // pointer arithmetic, not integer round trip: the loads stay global_load, not flat_load
     const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3];   // byte 12 lies in dword 3 for every o
     const uint32_t sh = o * 8;
     const uint32_t e0 = __funnelshift_r(d0, d1, sh), e1 = __funnelshift_r(d1, d2, sh);
