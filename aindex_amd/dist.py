@@ -111,3 +111,79 @@ def lookup_sharded(index, kmers_u8, device=None):
     a = np.ascontiguousarray(kmers_u8, dtype=np.uint8).reshape(-1, index.k)
     lo, hi = shard_range(a.shape[0], rank, world)
     return lo, hi, index.tf_ascii(a[lo:hi])
+
+
+# ---- distinct k-mer discovery (K1) across ranks: the one step of the path with a real exchange ------
+def _owner_of(keys, world: int):
+    """Owning rank of every 2-bit key: splitmix64 finaliser of the code, modulo the world size. int64 tensors carry
+    u64 bit patterns (multiplication wraps; logical shifts are spelled out because `>>` on int64 is arithmetic)."""
+    import torch
+
+    def lsr(x, s):
+        return (x >> s) & ((1 << (64 - s)) - 1)
+
+    def i64(c):                                       # a u64 constant as the int64 with the same bit pattern
+        return c - (1 << 64) if c >= (1 << 63) else c
+
+    z = keys + i64(0x9E3779B97F4A7C15)
+    z = (z ^ lsr(z, 30)) * i64(0xBF58476D1CE4E5B9)
+    z = (z ^ lsr(z, 27)) * i64(0x94D049BB133111EB)
+    z = z ^ lsr(z, 31)
+    return lsr(z, 1) % world                          # non-negative before the modulo
+
+
+def exchange_merge_counts(keys, counts, min_count: int = 1):
+    """One all-to-all of (key, count) pairs: every rank sends each of its locally distinct keys to the key's owner and
+    sums what it receives. keys: int64 (u64 bit patterns, any order, distinct per rank), counts: int64.
+    Returns this rank's share of the GLOBAL distinct set: (keys ascending, summed counts >= min_count). The shares of
+    all ranks are disjoint and their union is the unsharded result. Works on CPU tensors (gloo) and device tensors
+    (nccl = RCCL; with gloo the exchange itself is staged through host memory)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    if world > 1 or (world == 1 and os.environ.get("AIX_FORCE_DIST") and dist.is_initialized()):
+        owner = _owner_of(keys, world)
+        order = torch.argsort(owner, stable=True)
+        keys, counts = keys[order].contiguous(), counts[order].contiguous()
+        send_sizes = torch.bincount(owner, minlength=world).to(torch.int64)
+        dev = keys.device
+        via_host = dist.get_backend() != "nccl" and dev.type != "cpu"
+        xdev = torch.device("cpu") if via_host else dev
+        send_sizes_x = send_sizes.to(xdev)
+        recv_sizes_x = torch.empty(world, dtype=torch.int64, device=xdev)
+        dist.all_to_all_single(recv_sizes_x, send_sizes_x)
+        ins, outs = send_sizes_x.tolist(), recv_sizes_x.tolist()
+        rk = torch.empty(sum(outs), dtype=torch.int64, device=xdev)
+        rc = torch.empty(sum(outs), dtype=torch.int64, device=xdev)
+        dist.all_to_all_single(rk, keys.to(xdev), output_split_sizes=outs, input_split_sizes=ins)
+        dist.all_to_all_single(rc, counts.to(xdev), output_split_sizes=outs, input_split_sizes=ins)
+        keys, counts = rk.to(dev), rc.to(dev)
+    # local merge: equal keys from different ranks are summed (keys compare as u64: every valid code is < 2^62)
+    ukeys, inv = torch.unique(keys, sorted=True, return_inverse=True)
+    sums = torch.zeros(ukeys.numel(), dtype=torch.int64, device=keys.device)
+    sums.index_add_(0, inv, counts)
+    if min_count > 1:
+        keep = sums >= min_count
+        ukeys, sums = ukeys[keep], sums[keep]
+    return ukeys, sums
+
+
+def count_distinct_sharded(plain: bytes, k: int, canon_mode: int = 2, min_count: int = 1, device: int = 0):
+    """kmer_counter over ranks: every rank counts the distinct canonical k-mers of its record-aligned share of a PLAIN
+    buffer on its GPU (window-code kernel + sort / run-length), then ONE exchange routes each key to its owner.
+    Returns this rank's (keys, counts) share as device int64 tensors; min_count applies to the global counts."""
+    import torch
+    from . import counting
+    rank, world, _ = rank_world()
+    mine = shard_lines(plain, rank, world)
+    t = torch.frombuffer(bytearray(mine) if mine else bytearray(1), dtype=torch.uint8)[: len(mine)].to(f"cuda:{device}")
+    keys, counts = counting.count_distinct_t(t, k, canon_mode, 1)
+    return exchange_merge_counts(keys, counts, min_count)
+
+
+def coverage_sharded(index, seqs, cutoff: int = 0):
+    """Per-position tf profiles with the SEQUENCES split into contiguous ranges over the ranks (index replicated, no
+    collective on the data path). Every rank returns (lo, hi, list of uint32 arrays) for its own range."""
+    rank, world, _ = rank_world()
+    lo, hi = shard_range(len(seqs), rank, world)
+    return lo, hi, index.coverage(seqs[lo:hi], cutoff)

@@ -1,0 +1,73 @@
+"""N>1 worker on GPU(s): every sharded entry point of aindex_amd.dist against the unsharded HIP result and the oracle.
+Launched by test_gpu_parity.py with 2 gloo ranks sharing cuda:0 (the box has one GPU), and with 1 nccl rank
+(AIX_FORCE_DIST=1) so that the RCCL calls themselves run. The oracle is only the checker here."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as O                                    # noqa: E402
+from aindex_amd import _lib, dist as adist       # noqa: E402
+from aindex_amd.engine import Index                        # noqa: E402
+
+
+def gather_var(t):
+    """all_gather of int64 tensors of different lengths (through host memory; test plumbing)."""
+    world = dist.get_world_size()
+    t = t.cpu()
+    if world == 1:
+        return t
+    n = torch.tensor([t.numel()], dtype=torch.int64)
+    ns = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(ns, n)
+    m = max(int(x.item()) for x in ns)
+    pad = torch.zeros(m, dtype=torch.int64); pad[: t.numel()] = t
+    outs = [torch.empty(m, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(outs, pad)
+    return torch.cat([o[: int(x.item())] for o, x in zip(outs, ns)])
+
+
+def main():
+    rank, world, _ = adist.init()
+    torch.cuda.set_device(0)
+    prefix = os.path.join(ROOT, "tests", "golden", "small23", "small23")
+    reads = open(prefix + ".reads", "rb").read()
+    orc = O.OracleIndex23.from_prefix(prefix)
+    with Index.open_23(prefix + ".pf", prefix + ".tf.bin", prefix + ".kmers.bin", device=0) as ix:
+        tf = adist.count23_sharded(ix, reads, _lib.CANON_REF_X86, device=0)
+        assert np.array_equal(tf.cpu().numpy().view(np.uint32), orc.tf_array())
+        seqs = [l.replace(b"~", b"N") for l in reads.split(b"\n")[:41]]
+        lo, hi, prof = adist.coverage_sharded(ix, seqs, 2)
+        for s, p in zip(seqs[lo:hi], prof):
+            assert np.array_equal(p, orc.coverage(s, 2))
+        cnt = torch.tensor([hi - lo], dtype=torch.int64, device="cuda:0" if dist.get_backend() == "nccl" else "cpu")
+        adist.all_reduce_sum_(cnt)
+        assert int(cnt.item()) == len(seqs)
+    plain = reads.replace(b"~", b"\n")
+    assert plain.endswith(b"\n")
+    fasta = b"".join(b">r\n" + l + b"\n" for l in plain.split(b"\n") if l)
+    for k, mode, minc in ((23, _lib.CANON_REF_X86, 1), (23, _lib.CANON_TRUE_RC, 2), (13, _lib.CANON_TRUE_RC, 3)):
+        sk, sc = adist.count_distinct_sharded(plain, k, mode, minc, device=0)
+        assert sk.is_cuda and bool(torch.all(adist._owner_of(sk, world) == rank))
+        allk, allc = gather_var(sk).numpy().view(np.uint64), gather_var(sc).numpy().astype(np.uint64)
+        o = np.argsort(allk, kind="stable")
+        fk, fc = O.count_distinct(fasta, k, mode, minc)
+        assert fk.shape[0] > 100 and np.array_equal(allk[o], fk) and np.array_equal(allc[o], fc.astype(np.uint64)), (k, mode, minc)
+    from pf13 import pf13_path
+    with Index.open_13(pf13_path(), None, device=0) as ix13:
+        got = adist.count13_sharded(ix13, plain, device=0).cpu().numpy().view(np.uint64)
+        m = O.OracleMphf(pf13_path())
+        assert np.array_equal(got, O.count13(m, plain, _lib.FMT_PLAIN))
+    adist.barrier()
+    if rank == 0:
+        print("DIST_GPU_OK", dist.get_backend(), world)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

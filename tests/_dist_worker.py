@@ -47,6 +47,30 @@ def main():
         bufs = [o[: h - l] for o, (l, h) in zip(outs, sizes)]
     got = torch.cat(bufs).numpy().view(np.uint32)
     assert np.array_equal(got, orc.tf_batch(q))
+    # K1 across ranks: per-rank distinct sets (oracle on this rank's reads) -> ONE all-to-all by key owner -> summed counts;
+    # the union of the ranks' shares must equal the unsharded run, min_count applied to the GLOBAL counts
+    lines = [l for l in reads.split(b"\n") if l]
+    lo, hi = adist.shard_range(len(lines), rank, world)
+    fasta = lambda ls: b"".join(b">r\n" + l.replace(b"~", b"\n>m\n") + b"\n" for l in ls)
+    for k, mode, minc in ((23, 1, 1), (23, 2, 2), (13, 2, 3)):
+        lk, lc = O.count_distinct(fasta(lines[lo:hi]), k, mode, 1)
+        sk, sc = adist.exchange_merge_counts(torch.from_numpy(lk.view(np.int64).copy()), torch.from_numpy(lc.astype(np.int64)), minc)
+        assert torch.all(adist._owner_of(sk, world) == rank)                   # only keys this rank owns
+        assert torch.all(sk[1:] > sk[:-1]) if sk.numel() > 1 else True
+        sz = torch.tensor([sk.numel()], dtype=torch.int64)
+        szs = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(szs, sz)
+        m = max(int(x.item()) for x in szs)
+        pk = torch.full((m,), -1, dtype=torch.int64); pk[: sk.numel()] = sk
+        pc = torch.zeros(m, dtype=torch.int64); pc[: sc.numel()] = sc
+        gk = [torch.empty(m, dtype=torch.int64) for _ in range(world)]
+        gc = [torch.empty(m, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(gk, pk); dist.all_gather(gc, pc)
+        allk = torch.cat([g[: int(n.item())] for g, n in zip(gk, szs)]).numpy().view(np.uint64)
+        allc = torch.cat([g[: int(n.item())] for g, n in zip(gc, szs)]).numpy().astype(np.uint64)
+        o = np.argsort(allk, kind="stable")
+        fk, fc = O.count_distinct(fasta(lines), k, mode, minc)
+        assert fk.shape[0] > 100 and np.array_equal(allk[o], fk) and np.array_equal(allc[o], fc.astype(np.uint64)), (k, mode, minc)
     t = adist.all_reduce_max_float(float(rank + 1))
     assert t == 2.0
     adist.barrier()

@@ -775,3 +775,22 @@ def test_early_exit_walk_on_off(canon_case, ix23, q23):
     from aindex_amd import engine
     li = ix.lines_ascii_t(engine.synth_kmers_t(7, 200_000, 23)).cpu().numpy()
     assert 1.0 <= float((li & 15).mean()) < 2.0          # absent keys stop after ~1.35 records on average
+
+
+# ------------------------------------------------------------------------------------------------
+# N > 1 on the GPU: every sharded entry point of aindex_amd.dist (tests/_dist_gpu_worker.py). Two gloo ranks share
+# cuda:0 (this box has one GPU); one nccl rank runs the same code through RCCL (all_reduce, all_to_all, barrier).
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("backend,nproc", [("gloo", 2), ("nccl", 1)])
+def test_sharded_entry_points_multi_process(backend, nproc):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", AIX_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if nproc == 1:
+        env["AIX_FORCE_DIST"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", "29683" if nproc == 2 else "29684", os.path.join(root, "tests", "_dist_gpu_worker.py")]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0 and f"DIST_GPU_OK {backend} {nproc}" in out, out[-4000:]
