@@ -557,16 +557,22 @@ extern "C" int aix_count13_dev(aix_index_t* h, const char* d_plain, uint64_t len
     std::lock_guard<std::mutex> lk(h->count_mutex);
     hipStream_t s = (hipStream_t)stream;
     const bool use_atomics = getenv("AIX_COUNT13_ATOMICS") != nullptr;             // A/B switch for measurements / tests
-    if (use_atomics || len >= (1ull << 32)) {
+    if (use_atomics) {
         if (!h->scratch13) {
             HIPCHK(hipMalloc((void**)&h->scratch13, 8 * AIX_TOTAL_13MERS));
             h->device_bytes += 8 * AIX_TOTAL_13MERS;
         }
-        // 1.4e9-window launches and beyond: scattered u64 memory-side atomics (slower, no size limit)
+        // scattered u64 memory-side atomics into the code-ordered table (slower; kept as the independent cross-check)
         HIPCHK(hipMemsetAsync(h->scratch13, 0, 8 * AIX_TOTAL_13MERS, s));
         HIPCHK(launch_count13_plain((const uint8_t*)d_plain, len, h->scratch13, s));
     } else {
-        const uint64_t need = count13_workspace_bytes(len);
+        // The partitioned path indexes windows with 32 bits: buffers are cut into pieces of at most `piece` window starts.
+        // A window belongs to the piece that holds its first byte; a piece is handed its 12 following bytes as well, so the
+        // cut needs no record boundary and every window is counted exactly once. Pieces after the first add to the table.
+        uint64_t piece = 1ull << 31;
+        if (const char* e = getenv("AIX_COUNT13_PIECE")) { const uint64_t v = strtoull(e, nullptr, 10); if (v >= 1 && v <= (1ull << 31)) piece = v; }
+        const uint64_t nwin = len >= 13 ? len - 12 : 0;
+        const uint64_t need = count13_workspace_bytes(std::min(nwin, piece) + 12);
         if (need > h->work13_bytes) {
             HIPCHK(hipStreamSynchronize(s));
             if (h->work13) { (void)hipFree(h->work13); h->device_bytes -= h->work13_bytes; h->work13 = nullptr; h->work13_bytes = 0; }
@@ -575,7 +581,10 @@ extern "C" int aix_count13_dev(aix_index_t* h, const char* d_plain, uint64_t len
             h->device_bytes += need;
         }
         HIPCHK(hipMemsetAsync(d_tf_out, 0, 8 * AIX_TOTAL_13MERS, s));
-        HIPCHK(launch_count13_partitioned((const uint8_t*)d_plain, len, h->work13, nullptr, h->perm13, d_tf_out, s));   // fused permutation
+        for (uint64_t first = 0; first < nwin; first += piece) {
+            const uint64_t w = std::min(piece, nwin - first);
+            HIPCHK(launch_count13_partitioned((const uint8_t*)d_plain + first, w + 12, h->work13, nullptr, h->perm13, d_tf_out, first != 0, s));   // fused permutation
+        }
         return AIX_OK;
     }
     HIPCHK(hipMemsetAsync(d_tf_out, 0, 8 * AIX_TOTAL_13MERS, s));
@@ -930,9 +939,10 @@ extern "C" int aix_positions_fill(aix_index_t* h, const char* reads, uint64_t le
                                   uint64_t* total_out) {
     if (!h || !indices_out || (len && !reads)) return AIX_ERR_ARG;
     if (h->k != 23) return AIX_ERR_MODE;
-    if (len >> 32) return AIX_ERR_UNSUPPORTED;
     DevGuard g(h->device);
     const uint64_t n = h->n;
+    uint64_t piece = 0;                                                        // 0: default (2^30 windows per sort)
+    if (const char* e = getenv("AIX_POSITIONS_PIECE")) piece = strtoull(e, nullptr, 10);   // test hook: exercise the piece logic at small sizes
     DevBuf dind;
     HIPCHK(dind.alloc(8 * (n + 1)));
     if (n) HIPCHK(positions_indices(h->dev(), (uint64_t*)dind.p, 0));
@@ -948,7 +958,7 @@ extern "C" int aix_positions_fill(aix_index_t* h, const char* reads, uint64_t le
     HIPCHK(dpos.alloc(8 * total));
     if (len) HIPCHK(hipMemcpy(dreads.p, reads, len, hipMemcpyHostToDevice));
     HIPCHK(hipMemset(dpos.p, 0, 8 * total));
-    HIPCHK(positions_fill(h->dev(), (const uint8_t*)dreads.p, len, a2_start(reads, len), (const uint64_t*)dind.p, (uint64_t*)dpos.p, 0));
+    HIPCHK(positions_fill(h->dev(), (const uint8_t*)dreads.p, len, a2_start(reads, len), (const uint64_t*)dind.p, (uint64_t*)dpos.p, piece, 0));
     HIPCHK(hipMemcpy(positions_out, dpos.p, 8 * total, hipMemcpyDeviceToHost));
     return AIX_OK;
 }

@@ -193,7 +193,8 @@ __global__ void __launch_bounds__(C13_TB) k_c13_split(const uint8_t* __restrict_
 // mphf-ordered output (pre-zeroed by the caller): out[perm[code]] = count. Otherwise every bin of the
 // code-ordered table is stored.
 __global__ void __launch_bounds__(C13_TB) k_c13_hist(const uint16_t* __restrict__ parts, const unsigned long long* __restrict__ part_base,
-                                                    unsigned long long* __restrict__ table, const uint32_t* __restrict__ perm, uint64_t* __restrict__ out_mphf) {
+                                                    unsigned long long* __restrict__ table, const uint32_t* __restrict__ perm, uint64_t* __restrict__ out_mphf,
+                                                    int accumulate) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t* h = (uint32_t*)smem;                              // [BINS]
     for (uint32_t p = blockIdx.x; p < (uint32_t)C13_P; p += gridDim.x) {
@@ -228,10 +229,11 @@ __global__ void __launch_bounds__(C13_TB) k_c13_hist(const uint16_t* __restrict_
         if (perm) {
             for (int i = threadIdx.x; i < C13_BINS; i += C13_TB) {
                 const uint32_t c = h[i];
-                if (c) { const uint32_t slot = perm[base + i]; if (slot < 67108864u) out_mphf[slot] = c; }
+                // every bin has exactly one writer per launch, launches of one call are ordered on the stream: plain += is exact
+                if (c) { const uint32_t slot = perm[base + i]; if (slot < 67108864u) out_mphf[slot] = accumulate ? out_mphf[slot] + c : (uint64_t)c; }
             }
         } else {
-            for (int i = threadIdx.x; i < C13_BINS; i += C13_TB) table[base + i] = h[i];
+            for (int i = threadIdx.x; i < C13_BINS; i += C13_TB) table[base + i] = accumulate ? table[base + i] + h[i] : (unsigned long long)h[i];
         }
         __syncthreads();
     }
@@ -246,7 +248,7 @@ uint64_t count13_workspace_bytes(uint64_t len) {
 }
 
 hipError_t launch_count13_partitioned(const uint8_t* buf, uint64_t len, void* workspace, unsigned long long* table, const uint32_t* perm,
-                                      uint64_t* out_mphf, hipStream_t s) {
+                                      uint64_t* out_mphf, int accumulate, hipStream_t s) {
     const uint64_t nwin = len >= 13 ? len - 12 : 0;
     unsigned long long* part_count = (unsigned long long*)workspace;
     unsigned long long* part_base = part_count + C13_P;
@@ -266,7 +268,7 @@ hipError_t launch_count13_partitioned(const uint8_t* buf, uint64_t len, void* wo
     hipLaunchKernelGGL(k_c13_colscan, dim3(C13_P / C13_TB), dim3(C13_TB), 0, s, cnt, grid, part_count);
     hipLaunchKernelGGL(k_c13_scan, dim3(1), dim3(C13_TB), 0, s, part_count, part_base);
     hipLaunchKernelGGL(k_c13_split, dim3(grid), dim3(C13_TB), split_lds, s, buf, len, ntiles, part_base, cnt, parts);
-    hipLaunchKernelGGL(k_c13_hist, dim3(C13_P), dim3(C13_TB), hist_lds, s, parts, part_base, table, perm, out_mphf);
+    hipLaunchKernelGGL(k_c13_hist, dim3(C13_P), dim3(C13_TB), hist_lds, s, parts, part_base, table, perm, out_mphf, accumulate);
     return hipGetLastError();
 }
 

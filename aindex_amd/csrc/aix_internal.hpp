@@ -52,7 +52,7 @@ hipError_t launch_count13_plain(const uint8_t* buf, uint64_t len, unsigned long 
 uint64_t count13_workspace_bytes(uint64_t len);
 // perm/out_mphf set: counters are written straight into the (pre-zeroed) mphf-ordered output; else into table_code
 hipError_t launch_count13_partitioned(const uint8_t* buf, uint64_t len, void* workspace, unsigned long long* table_code, const uint32_t* perm,
-                                      uint64_t* out_mphf, hipStream_t s);
+                                      uint64_t* out_mphf, int accumulate, hipStream_t s);
 hipError_t launch_scatter13_to_mphf(const uint32_t* perm, const unsigned long long* table_code, uint64_t* out_mphf, hipStream_t s);
 hipError_t launch_count23_fixed(const IndexDev& ix, const uint8_t* buf, uint64_t len, int canon_mode, uint32_t* tf_out, hipStream_t s);
 
@@ -63,7 +63,7 @@ hipError_t launch_gather(const uint8_t* table, uint64_t n_elems, int elem_bytes,
 // positions index (aix_positions.hip)
 hipError_t positions_indices(const IndexDev& ix, uint64_t* d_indices /* n+1 */, hipStream_t s);
 hipError_t positions_fill(const IndexDev& ix, const uint8_t* d_reads, uint64_t len, uint64_t start, const uint64_t* d_indices, uint64_t* d_positions,
-                          hipStream_t s);
+                          uint64_t piece, hipStream_t s);
 
 // distinct k-mers = sort + run-length of window codes; outputs hipMalloc'd (caller frees), d_codes is clobbered
 hipError_t distinct_from_codes(uint64_t* d_codes, uint64_t nwin, int k, uint64_t min_count, uint64_t** d_keys_out, uint32_t** d_counts_out, uint64_t* n_out,

@@ -6,6 +6,7 @@
 // §8a-A2). Here every window's bucket is computed in parallel, then a STABLE radix sort by bucket (rocPRIM) of the
 // window offsets (a counting iterator, i.e. already ascending) yields each bucket's offsets in ascending order —
 // exactly the 1-thread reference result, deterministically — and the first tf[h] of them are placed.
+#include <algorithm>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -73,15 +74,29 @@ __global__ void __launch_bounds__(kB) k_a2_first(const uint32_t* __restrict__ sk
         if (h < n && (j == 0 || skeys[j - 1] != h)) first[h] = (uint32_t)j;
     }
 }
+// `filled[h]` = occurrences of bucket h in the pieces before this one (the reference's ppositions[h] counter, hash.cpp:1037)
 __global__ void __launch_bounds__(kB) k_a2_place(const IndexDev ix, const uint32_t* __restrict__ skeys, const uint32_t* __restrict__ svals, uint64_t nwin,
-                                                const uint32_t* __restrict__ first, const uint64_t* __restrict__ indices, uint64_t* __restrict__ positions) {
+                                                uint64_t piece_first, const uint32_t* __restrict__ first, const uint32_t* __restrict__ filled,
+                                                const uint64_t* __restrict__ indices, uint64_t* __restrict__ positions) {
     const uint64_t stride = (uint64_t)gridDim.x * kB;
     const uint32_t n = (uint32_t)ix.n;
     for (uint64_t j = (uint64_t)blockIdx.x * kB + threadIdx.x; j < nwin; j += stride) {
         const uint32_t h = skeys[j];
         if (h >= n) continue;
-        const uint64_t rank = j - first[h];
-        if (rank < ix.keys[h].tf) positions[indices[h] + rank] = (uint64_t)svals[j] + 1;     // :1037-1040, 1-based offsets
+        const uint64_t rank = (uint64_t)filled[h] + (j - first[h]);
+        if (rank < ix.keys[h].tf) positions[indices[h] + rank] = piece_first + svals[j] + 1;     // :1037-1040, 1-based offsets
+    }
+}
+// after a piece has been placed: filled[h] += occurrences of h in the piece (saturating; tf is 32 bits, so a saturated
+// counter can never admit another offset). One writer per bucket: the lane that holds the last element of h's run.
+__global__ void __launch_bounds__(kB) k_a2_advance(const uint32_t* __restrict__ skeys, uint64_t nwin, uint32_t n, const uint32_t* __restrict__ first,
+                                                  uint32_t* __restrict__ filled) {
+    const uint64_t stride = (uint64_t)gridDim.x * kB;
+    for (uint64_t j = (uint64_t)blockIdx.x * kB + threadIdx.x; j < nwin; j += stride) {
+        const uint32_t h = skeys[j];
+        if (h >= n || (j + 1 < nwin && skeys[j + 1] == h)) continue;
+        const uint64_t tot = (uint64_t)filled[h] + (j - first[h] + 1);
+        filled[h] = tot > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)tot;
     }
 }
 
@@ -103,32 +118,42 @@ hipError_t positions_indices(const IndexDev& ix, uint64_t* d_indices, hipStream_
     return e;
 }
 
-// positions (device, pre-zeroed, indices[n] entries) for a reads buffer in HBM. len < 2^32.
+// positions (device, pre-zeroed, indices[n] entries) for a reads buffer in HBM. Windows are indexed with 32 bits inside a
+// piece; longer buffers go piece by piece in ascending order, the per-bucket fill counters carried from piece to piece, which
+// keeps every bucket's offsets ascending (the reference's 1-thread order) for any buffer length.
 hipError_t positions_fill(const IndexDev& ix, const uint8_t* d_reads, uint64_t len, uint64_t start, const uint64_t* d_indices, uint64_t* d_positions,
-                          hipStream_t s) {
+                          uint64_t piece, hipStream_t s) {
     if (len < 23 || ix.n == 0) return hipSuccess;
-    const uint64_t nwin = len - 22;
-    uint32_t *keys = nullptr, *skeys = nullptr, *svals = nullptr, *first = nullptr;
+    const uint64_t nwin_all = len - 22;
+    if (piece == 0 || piece > (1ull << 31)) piece = 1ull << 30;
+    const uint64_t pw = std::min(piece, nwin_all);
+    uint32_t *keys = nullptr, *skeys = nullptr, *svals = nullptr, *first = nullptr, *filled = nullptr;
     void* tmp = nullptr;
-    hipError_t e = hipMalloc((void**)&keys, 4 * nwin);
-    if (e == hipSuccess) e = hipMalloc((void**)&skeys, 4 * nwin);
-    if (e == hipSuccess) e = hipMalloc((void**)&svals, 4 * nwin);
+    hipError_t e = hipMalloc((void**)&keys, 4 * pw);
+    if (e == hipSuccess) e = hipMalloc((void**)&skeys, 4 * pw);
+    if (e == hipSuccess) e = hipMalloc((void**)&svals, 4 * pw);
     if (e == hipSuccess) e = hipMalloc((void**)&first, 4 * ix.n);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_a2_probe, dim3(grid_of(nwin)), dim3(kB), 0, s, ix, d_reads, nwin, start, keys);
-        e = hipGetLastError();
-    }
+    if (e == hipSuccess) e = hipMalloc((void**)&filled, 4 * ix.n);
+    if (e == hipSuccess) e = hipMemsetAsync(filled, 0, 4 * ix.n, s);
     unsigned end_bit = 1;
     while (end_bit < 32 && (ix.n >> end_bit)) ++end_bit;                        // keys are in [0, n]
     size_t tmp_bytes = 0;
     rocprim::counting_iterator<uint32_t> iota(0);
-    if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, skeys, iota, svals, (size_t)nwin, 0u, end_bit, s);
+    if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, skeys, iota, svals, (size_t)pw, 0u, end_bit, s);
     if (e == hipSuccess) e = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1);
-    if (e == hipSuccess) e = rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, skeys, iota, svals, (size_t)nwin, 0u, end_bit, s);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_a2_first, dim3(grid_of(nwin)), dim3(kB), 0, s, skeys, nwin, (uint32_t)ix.n, first);
-        hipLaunchKernelGGL(k_a2_place, dim3(grid_of(nwin)), dim3(kB), 0, s, ix, skeys, svals, nwin, first, d_indices, d_positions);
+    for (uint64_t w0 = 0; e == hipSuccess && w0 < nwin_all; w0 += pw) {
+        const uint64_t nwin = std::min(pw, nwin_all - w0);
+        const uint64_t rel_start = start > w0 ? start - w0 : 0;               // windows before `start` get no bucket (hash.cpp:973-986)
+        hipLaunchKernelGGL(k_a2_probe, dim3(grid_of(nwin)), dim3(kB), 0, s, ix, d_reads + w0, nwin, rel_start, keys);
         e = hipGetLastError();
+        size_t tb = tmp_bytes;                                                  // sized for pw >= nwin elements
+        if (e == hipSuccess) e = rocprim::radix_sort_pairs(tmp, tb, keys, skeys, iota, svals, (size_t)nwin, 0u, end_bit, s);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_a2_first, dim3(grid_of(nwin)), dim3(kB), 0, s, skeys, nwin, (uint32_t)ix.n, first);
+            hipLaunchKernelGGL(k_a2_place, dim3(grid_of(nwin)), dim3(kB), 0, s, ix, skeys, svals, nwin, w0, first, filled, d_indices, d_positions);
+            if (w0 + pw < nwin_all) hipLaunchKernelGGL(k_a2_advance, dim3(grid_of(nwin)), dim3(kB), 0, s, skeys, nwin, (uint32_t)ix.n, first, filled);
+            e = hipGetLastError();
+        }
     }
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (tmp) (void)hipFree(tmp);
@@ -136,6 +161,7 @@ hipError_t positions_fill(const IndexDev& ix, const uint8_t* d_reads, uint64_t l
     if (skeys) (void)hipFree(skeys);
     if (svals) (void)hipFree(svals);
     if (first) (void)hipFree(first);
+    if (filled) (void)hipFree(filled);
     return e;
 }
 

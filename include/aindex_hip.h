@@ -190,7 +190,8 @@ int aix_window_codes_dev(const char* d_plain, uint64_t len, int k, int canon_mod
  * for every 23-byte window of the `.reads` buffer without '\n', '~', 'N', probing only the numerically smaller
  * strand, positions[indices[h] + slot] = offset + 1 for the first tf[h] occurrences in ascending offset order —
  * the result of the reference run with ONE thread (lu_compressed_worker, src/hash.cpp:960-1060; its multi-thread
- * slot order is schedule dependent). positions_out may be NULL to query *total_out = indices[n] first. len < 2^32. */
+ * slot order is schedule dependent). positions_out may be NULL to query *total_out = indices[n] first.
+ * Any length: buffers of more than 2^30 windows are filled piece by piece, per-bucket fill counters carried over. */
 int aix_positions_fill(aix_index_t* h, const char* reads, uint64_t len, uint64_t* indices_out, uint64_t* positions_out,
                        uint64_t positions_cap, uint64_t* total_out);
 /* K1 complete: replaces `kmer_counter <in.fa> <k> <out> [-t N] [-m min]` (src/count_kmers.cpp:235-382): the set of

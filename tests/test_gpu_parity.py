@@ -385,6 +385,79 @@ def test_positions_fill_vs_oracle_true_canonical(canon_case):
     assert (pos != 0).sum() > 100_000
 
 
+@pytest.mark.parametrize("piece", [1, 7, 1000, 50_000])
+def test_positions_fill_in_pieces(ix23, gold, small23_prefix, canon_case, piece):
+    """Buffers of more than 2^30 windows are filled piece by piece with the per-bucket fill counters carried over;
+    AIX_POSITIONS_PIECE shrinks the piece so that this runs at test sizes. Every piece size must reproduce the reference's
+    1-thread files (golden) and the oracle (tf-capped buckets, start quirk, separators on piece borders)."""
+    os.environ["AIX_POSITIONS_PIECE"] = str(piece)
+    try:
+        z = np.load(os.path.join(gold, "small23", "aindex.npz"))
+        reads = open(small23_prefix + ".reads", "rb").read()
+        if piece < 1000:
+            reads = reads[: 6000]
+            want_ind, want_pos = O.OracleIndex23.from_prefix(small23_prefix).positions(reads)
+        else:
+            want_ind, want_pos = z["indices"], z["index"]
+        indices, pos = ix23.positions_fill(reads)
+        assert np.array_equal(indices, want_ind) and np.array_equal(pos, want_pos)
+        if piece >= 1000:
+            ix, orc = canon_case["ix"], canon_case["orc"]
+            asc = synth.genome_ascii(23, 300_000)
+            r = synth.reads_plain(43, asc, 1500, 150, rc_fraction_half=True, n_rate_ppm=2000).reshape(-1, 151).copy()
+            r[::7, 150] = ord("~")
+            r[3::40] |= 0x20
+            r[3::40, 150] = ord("\n")
+            buf = b"?AC\n" + r.tobytes() + r[:700].tobytes()            # repeated reads overflow their buckets (slot >= tf is dropped)
+            want_ind, want_pos = orc.positions(buf)
+            indices, pos = ix.positions_fill(buf)
+            assert np.array_equal(indices, want_ind) and np.array_equal(pos, want_pos)
+    finally:
+        del os.environ["AIX_POSITIONS_PIECE"]
+
+
+@pytest.mark.slow
+def test_positions_fill_beyond_4gib(canon_case):
+    """4.53 GB of reads (> 2^32 bytes): five pieces (default 2^30 windows) == three pieces (2^31); every stored offset
+    points at a window whose numerically smaller strand is the bucket's key, ascending inside the bucket, and a bucket is
+    short only when the buffer holds fewer than tf occurrences (none here)."""
+    from aindex_amd import engine
+    ix = canon_case["ix"]
+    g = engine.synth_genome_t(23, 300_000)
+    reads_t = engine.synth_reads_t(44, g, 30_000_000, 150, rc_half=True, n_rate_ppm=500)
+    assert reads_t.numel() > (1 << 32)
+    reads = reads_t.cpu().numpy()
+    del reads_t
+    buf = reads.tobytes()
+    ind, pos = ix.positions_fill(buf)
+    os.environ["AIX_POSITIONS_PIECE"] = str(1 << 31)
+    try:
+        ind2, pos2 = ix.positions_fill(buf)
+    finally:
+        del os.environ["AIX_POSITIONS_PIECE"]
+    assert np.array_equal(ind, ind2) and np.array_equal(pos, pos2)
+    tf = ix.tf_array()
+    checker = ix.checker_array()
+    assert int(ind[-1]) == int(tf.sum(dtype=np.uint64)) and np.all(pos != 0)            # 15 000x coverage fills every bucket
+    rng = np.random.default_rng(5)
+    for h in rng.integers(0, ix.n, size=300):
+        p = pos[int(ind[h]): int(ind[h + 1])].astype(np.int64) - 1
+        assert np.all(np.diff(p) > 0)
+        w = np.stack([reads[q: q + 23] for q in p])
+        codes = synth.encode_kmers(w)
+        canon = np.minimum(codes, synth.revcomp_codes(codes, 23))
+        assert np.all(canon == checker[h])
+    # the first tf offsets of a bucket are the first occurrences in the buffer: nothing before pos[first] matches
+    h = int(rng.integers(0, ix.n))
+    first = int(pos[int(ind[h])]) - 1
+    head = np.frombuffer(buf[: first + 22], dtype=np.uint8)
+    if head.shape[0] >= 23 and first < 5_000_000:
+        win = np.lib.stride_tricks.sliding_window_view(head, 23)
+        ok = np.all((win == 65) | (win == 67) | (win == 71) | (win == 84), axis=1)
+        c = synth.encode_kmers(win[ok])
+        assert not np.any(np.minimum(c, synth.revcomp_codes(c, 23)) == checker[h])
+
+
 def test_python_mirrors(gold, small23_prefix, tmp_path):
     from aindex_amd.aindex import AIndex, Strand
     q = load(gold, "small23", "queries.json")
@@ -721,6 +794,49 @@ def test_error_codes(small23_prefix, tmp_path):
         assert L.aix_tf_batch_ascii(ix._h, None, 5, None) == -1                                  # AIX_ERR_ARG
     assert L.aix_index_open_23(small23_prefix.encode() + b".pf", (small23_prefix + ".tf.bin").encode(), (small23_prefix + ".kmers.bin").encode(), 99,
                                C.byref(h)) == -1                                                 # no such device
+
+
+@pytest.mark.parametrize("piece", [1, 13, 1000, 77_777, 1 << 20])
+def test_count13_in_pieces(ix13, piece):
+    """Buffers beyond 2^31 windows are counted piece by piece (12-byte overlap, later pieces add to the table).
+    AIX_COUNT13_PIECE shrinks the piece so the cut logic runs at test sizes; every cut position must give the
+    one-piece result (cuts fall inside reads, on separators, on N)."""
+    import torch
+    from aindex_amd import engine
+    g = engine.synth_genome_t(13, 200_000)
+    reads = engine.synth_reads_t(15, g, 3000 if piece >= 1000 else 40, 150, n_rate_ppm=3000)
+    want = ix13.count13_t(reads).cpu().numpy().view(np.uint64)
+    os.environ["AIX_COUNT13_PIECE"] = str(piece)
+    try:
+        got = ix13.count13_t(reads).cpu().numpy().view(np.uint64)
+    finally:
+        del os.environ["AIX_COUNT13_PIECE"]
+    assert want.sum() > 0 and np.array_equal(got, want)
+
+
+@pytest.mark.slow
+def test_count13_beyond_4gib(ix13):
+    """30 M reads = 4.53 GB > 2^32 bytes: three pieces through the partitioned path == scattered atomics; the total is
+    the number of N-free windows (computed from a second, independent kernel: the window-code kernel)."""
+    import torch
+    from aindex_amd import counting, engine
+    g = engine.synth_genome_t(13, 4_000_000)
+    reads = engine.synth_reads_t(16, g, 30_000_000, 150, n_rate_ppm=1000)
+    assert reads.numel() > (1 << 32)
+    got = ix13.count13_t(reads)
+    os.environ["AIX_COUNT13_ATOMICS"] = "1"
+    try:
+        ref = ix13.count13_t(reads)
+    finally:
+        del os.environ["AIX_COUNT13_ATOMICS"]
+    assert bool(torch.equal(got, ref))
+    total = 0
+    step = 1 << 30
+    for lo in range(0, reads.numel() - 12, step):
+        c = counting.window_codes_t(reads[lo: lo + step + 12], 13, _lib.CANON_NONE)
+        total += int((c != -1).sum().item())
+        del c
+    assert int(got.sum().item()) == total
 
 
 def test_count13_skewed_and_crlf_inputs(ix13):
