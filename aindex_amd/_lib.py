@@ -18,6 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 HEADER = os.path.join(ROOT, "include", "aindex_hip.h")
 
 AIX_OK = 0
+AIX_ERR_CONFLICT = -12
 FMT_AUTO, FMT_PLAIN, FMT_FASTA, FMT_FASTQ = -1, 0, 1, 2
 CANON_NONE, CANON_REF_X86, CANON_TRUE_RC = 0, 1, 2
 TOTAL_13MERS = 4 ** 13
@@ -79,6 +80,9 @@ SIGNATURES = {
     "aix_count23_fixed_dev": (i32, [vp, vp, u64, i32, vp, vp]),
     "aix_count_distinct": (i32, [vp, u64, i32, i32, i32, u64, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]),
     "aix_positions_fill": (i32, [vp, vp, u64, vp, vp, u64, C.POINTER(u64)]),
+    "aix_positions_bucket_counts": (i32, [vp, vp, u64, i32, vp]),
+    "aix_positions_start": (i32, [vp, u64, C.POINTER(u64)]),
+    "aix_positions_fill_shard": (i32, [vp, vp, u64, i32, u64, vp, vp, u64]),
     "aix_window_codes_dev": (i32, [vp, u64, i32, i32, vp, vp]),
     "aix_normalize_reads": (i32, [vp, u64, i32, i32, vp, C.POINTER(u64)]),
     "aix_normalize_reads_dev": (i32, [vp, u64, i32, i32, vp, C.POINTER(u64), vp]),
@@ -92,6 +96,7 @@ SIGNATURES = {
     "aix_pf_build_ragged": (i32, [vp, vp, u64, C.POINTER(vp), C.POINTER(u64)]),
     "aix_pf_build_codes": (i32, [vp, u64, i32, C.POINTER(vp), C.POINTER(u64)]),
     "aix_index_scatter": (i32, [vp, u64, vp, vp, u64, i32, vp, vp]),
+    "aix_index_scatter_shard": (i32, [vp, u64, vp, vp, u64, u64, i32, vp, vp, vp]),
     "aix_index_build_23_codes_dev": (i32, [vp, u64, vp, vp, u64, i32, vp, C.POINTER(vp)]),
     "aix_pf_build_codes_dev": (i32, [vp, u64, i32, i32, vp, C.POINTER(vp), C.POINTER(u64)]),
     "aix_pf_build_all_13mers": (i32, [C.POINTER(vp), C.POINTER(u64)]),

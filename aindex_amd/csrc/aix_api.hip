@@ -254,52 +254,73 @@ extern "C" int aix_index_create_23(const void* pf_bytes, uint64_t pf_len, const 
 }
 
 // I1 on the device: scatter (key, count) pairs through the MPHF. Exactly one of d_keys / d_codes is set.
-static int scatter_device(aix_index* h, uint64_t n, const uint8_t* d_keys, const uint64_t* d_codes, const uint32_t* d_counts, uint64_t* d_checker,
-                          uint32_t* d_tf, hipStream_t s) {
+// n keys into nslots slots (nslots == n for a whole key set; a shard of the keys scatters into the full-size arrays).
+// occ_out (optional, device, ceil(nslots/32) words): bit h set <=> slot h was written by this call.
+static int scatter_device(aix_index* h, uint64_t n, uint64_t nslots, const uint8_t* d_keys, const uint64_t* d_codes, const uint32_t* d_counts,
+                          uint64_t* d_checker, uint32_t* d_tf, uint32_t* occ_out, hipStream_t s) {
     DevBuf occ, flag;
-    const uint64_t occ_bytes = 4 * ((n + 31) / 32);
+    const uint64_t occ_bytes = 4 * ((nslots + 31) / 32);
     HIPCHK(occ.alloc(occ_bytes));
     HIPCHK(flag.alloc(4));
     HIPCHK(hipMemsetAsync(occ.p, 0, occ_bytes, s));
     HIPCHK(hipMemsetAsync(flag.p, 0, 4, s));
-    HIPCHK(hipMemsetAsync(d_checker, 0, 8 * n, s));            // hash.cpp:836-844: arrays start zeroed
-    HIPCHK(hipMemsetAsync(d_tf, 0, 4 * n, s));
+    HIPCHK(hipMemsetAsync(d_checker, 0, 8 * nslots, s));       // hash.cpp:836-844: arrays start zeroed
+    HIPCHK(hipMemsetAsync(d_tf, 0, 4 * nslots, s));
     const IndexDev d = h->dev();
-    HIPCHK(launch_scatter23(d.m, n, d_keys, d_codes, d_counts, d_checker, d_tf, (uint32_t*)occ.p, (uint32_t*)flag.p, s));
+    HIPCHK(launch_scatter23(d.m, n, nslots, d_keys, d_codes, d_counts, d_checker, d_tf, (uint32_t*)occ.p, (uint32_t*)flag.p, s));
     uint32_t conflicts = 0;
     HIPCHK(hipMemcpyAsync(&conflicts, flag.p, 4, hipMemcpyDeviceToHost, s));
+    if (occ_out) HIPCHK(hipMemcpyAsync(occ_out, occ.p, occ_bytes, hipMemcpyDeviceToDevice, s));
     HIPCHK(hipStreamSynchronize(s));
     return conflicts ? AIX_ERR_CONFLICT : AIX_OK;
 }
 
-extern "C" int aix_index_scatter(const void* pf_bytes, uint64_t pf_len, const char* keys, const uint32_t* counts, uint64_t n, int device,
-                                 uint64_t* checker_out, uint32_t* tf_out) {
-    if (!pf_bytes || !keys || !checker_out || !tf_out || n == 0) return AIX_ERR_ARG;
+static int scatter_host(const void* pf_bytes, uint64_t pf_len, const char* keys, const uint32_t* counts, uint64_t n, uint64_t nslots, int device,
+                        uint64_t* checker_out, uint32_t* tf_out, uint32_t* occupied_out) {
     int st = check_device(device);
     if (st) return st;
     aix_index tmp;
-    tmp.device = device; tmp.k = 23; tmp.n = n;
+    tmp.device = device; tmp.k = 23; tmp.n = nslots;
     DevGuard g(device);
     st = upload_mphf(&tmp, (const uint8_t*)pf_bytes, pf_len);
     if (!st) {
-        DevBuf dk, dcnt, dc, dt;
+        DevBuf dk, dcnt, dc, dt, docc;
+        const uint64_t occ_bytes = 4 * ((nslots + 31) / 32);
         hipError_t e = dk.alloc(23 * n + 8);
-        if (e == hipSuccess) e = dc.alloc(8 * n);
-        if (e == hipSuccess) e = dt.alloc(4 * n);
-        if (e == hipSuccess && counts) e = dcnt.alloc(4 * n);
-        if (e == hipSuccess) e = hipMemcpy(dk.p, keys, 23 * n, hipMemcpyHostToDevice);
-        if (e == hipSuccess && counts) e = hipMemcpy(dcnt.p, counts, 4 * n, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = dc.alloc(8 * nslots);
+        if (e == hipSuccess) e = dt.alloc(4 * nslots);
+        if (e == hipSuccess && occupied_out) e = docc.alloc(occ_bytes);
+        if (e == hipSuccess && counts && n) e = dcnt.alloc(4 * n);
+        if (e == hipSuccess && n) e = hipMemcpy(dk.p, keys, 23 * n, hipMemcpyHostToDevice);
+        if (e == hipSuccess && counts && n) e = hipMemcpy(dcnt.p, counts, 4 * n, hipMemcpyHostToDevice);
         if (e != hipSuccess) { set_last_error(std::string("scatter staging: ") + hipGetErrorString(e)); st = AIX_ERR_HIP; }
-        if (!st) st = scatter_device(&tmp, n, (const uint8_t*)dk.p, nullptr, counts ? (const uint32_t*)dcnt.p : nullptr, (uint64_t*)dc.p, (uint32_t*)dt.p, 0);
-        if (!st) {
-            e = hipMemcpy(checker_out, dc.p, 8 * n, hipMemcpyDeviceToHost);
-            if (e == hipSuccess) e = hipMemcpy(tf_out, dt.p, 4 * n, hipMemcpyDeviceToHost);
+        if (!st) st = scatter_device(&tmp, n, nslots, (const uint8_t*)dk.p, nullptr, (counts && n) ? (const uint32_t*)dcnt.p : nullptr, (uint64_t*)dc.p,
+                                     (uint32_t*)dt.p, occupied_out ? (uint32_t*)docc.p : nullptr, 0);
+        if (!st || st == AIX_ERR_CONFLICT) {                       // a shard reports its conflict AND hands back what it wrote
+            const int keep = st;
+            e = hipMemcpy(checker_out, dc.p, 8 * nslots, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(tf_out, dt.p, 4 * nslots, hipMemcpyDeviceToHost);
+            if (e == hipSuccess && occupied_out) e = hipMemcpy(occupied_out, docc.p, occ_bytes, hipMemcpyDeviceToHost);
             if (e != hipSuccess) { set_last_error(std::string("scatter readback: ") + hipGetErrorString(e)); st = AIX_ERR_HIP; }
+            else st = keep;
         }
     }
     if (tmp.recs) (void)hipFree(tmp.recs);
     tmp.recs = nullptr;
     return st;
+}
+
+extern "C" int aix_index_scatter(const void* pf_bytes, uint64_t pf_len, const char* keys, const uint32_t* counts, uint64_t n, int device,
+                                 uint64_t* checker_out, uint32_t* tf_out) {
+    if (!pf_bytes || !keys || !checker_out || !tf_out || n == 0) return AIX_ERR_ARG;
+    return scatter_host(pf_bytes, pf_len, keys, counts, n, n, device, checker_out, tf_out, nullptr);
+}
+
+extern "C" int aix_index_scatter_shard(const void* pf_bytes, uint64_t pf_len, const char* keys, const uint32_t* counts, uint64_t n_keys, uint64_t n_slots,
+                                       int device, uint64_t* checker_out, uint32_t* tf_out, uint32_t* occupied_out) {
+    if (!pf_bytes || (n_keys && !keys) || !checker_out || !tf_out || !occupied_out || n_slots == 0 || n_keys > n_slots) return AIX_ERR_ARG;
+    if (n_slots >> 32) return AIX_ERR_UNSUPPORTED;
+    return scatter_host(pf_bytes, pf_len, keys, counts, n_keys, n_slots, device, checker_out, tf_out, occupied_out);
 }
 
 extern "C" int aix_index_build_23_codes_dev(const void* pf_bytes, uint64_t pf_len, const uint64_t* d_codes, const uint32_t* d_counts, uint64_t n,
@@ -319,7 +340,7 @@ extern "C" int aix_index_build_23_codes_dev(const void* pf_bytes, uint64_t pf_le
         hipError_t e = dc.alloc(8 * n);
         if (e == hipSuccess) e = dt.alloc(4 * n);
         if (e != hipSuccess) { set_last_error(std::string("index build: ") + hipGetErrorString(e)); st = AIX_ERR_HIP; }
-        if (!st) st = scatter_device(h, n, nullptr, d_codes, d_counts, (uint64_t*)dc.p, (uint32_t*)dt.p, (hipStream_t)stream);
+        if (!st) st = scatter_device(h, n, n, nullptr, d_codes, d_counts, (uint64_t*)dc.p, (uint32_t*)dt.p, nullptr, (hipStream_t)stream);
         if (!st) st = adopt_device_arrays(h, (const uint64_t*)dc.p, (const uint32_t*)dt.p, n, (hipStream_t)stream);
     }
     if (st) { destroy(h); return st; }
@@ -958,7 +979,60 @@ extern "C" int aix_positions_fill(aix_index_t* h, const char* reads, uint64_t le
     HIPCHK(dpos.alloc(8 * total));
     if (len) HIPCHK(hipMemcpy(dreads.p, reads, len, hipMemcpyHostToDevice));
     HIPCHK(hipMemset(dpos.p, 0, 8 * total));
-    HIPCHK(positions_fill(h->dev(), (const uint8_t*)dreads.p, len, a2_start(reads, len), (const uint64_t*)dind.p, (uint64_t*)dpos.p, piece, 0));
+    HIPCHK(positions_fill(h->dev(), (const uint8_t*)dreads.p, len, a2_start(reads, len), (const uint64_t*)dind.p, (uint64_t*)dpos.p, piece, nullptr, 0, 0));
+    HIPCHK(hipMemcpy(positions_out, dpos.p, 8 * total, hipMemcpyDeviceToHost));
+    return AIX_OK;
+}
+
+extern "C" int aix_positions_start(const char* reads, uint64_t len, uint64_t* start_out) {
+    if (!start_out || (len && !reads)) return AIX_ERR_ARG;
+    *start_out = a2_start(reads, len);
+    return AIX_OK;
+}
+
+// A2 over shards of the reads file (multi-GPU): tally, then fill with the counters of the earlier shards
+extern "C" int aix_positions_bucket_counts(aix_index_t* h, const char* reads, uint64_t len, int first_shard, uint64_t* counts_out) {
+    if (!h || !counts_out || (len && !reads)) return AIX_ERR_ARG;
+    if (h->k != 23) return AIX_ERR_MODE;
+    DevGuard g(h->device);
+    const uint64_t n = h->n;
+    if (n == 0) return AIX_OK;
+    DevBuf dreads, dcnt;
+    HIPCHK(dreads.alloc(len + 8));
+    HIPCHK(dcnt.alloc(8 * n));
+    if (len) HIPCHK(hipMemcpy(dreads.p, reads, len, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(dcnt.p, 0, 8 * n));
+    HIPCHK(positions_bucket_counts(h->dev(), (const uint8_t*)dreads.p, len, first_shard ? a2_start(reads, len) : 0, (unsigned long long*)dcnt.p, 0));
+    HIPCHK(hipMemcpy(counts_out, dcnt.p, 8 * n, hipMemcpyDeviceToHost));
+    return AIX_OK;
+}
+
+extern "C" int aix_positions_fill_shard(aix_index_t* h, const char* reads, uint64_t len, int first_shard, uint64_t base_offset, const uint32_t* filled_init,
+                                        uint64_t* positions_out, uint64_t positions_cap) {
+    if (!h || !positions_out || (len && !reads)) return AIX_ERR_ARG;
+    if (h->k != 23) return AIX_ERR_MODE;
+    DevGuard g(h->device);
+    const uint64_t n = h->n;
+    if (n == 0) return AIX_OK;
+    uint64_t piece = 0;
+    if (const char* e = getenv("AIX_POSITIONS_PIECE")) piece = strtoull(e, nullptr, 10);
+    DevBuf dind, dreads, dpos, dfill;
+    HIPCHK(dind.alloc(8 * (n + 1)));
+    HIPCHK(positions_indices(h->dev(), (uint64_t*)dind.p, 0));
+    uint64_t total = 0;
+    HIPCHK(hipMemcpy(&total, (const uint64_t*)dind.p + n, 8, hipMemcpyDeviceToHost));
+    if (positions_cap < total) return AIX_ERR_ARG;
+    if (total == 0) return AIX_OK;
+    HIPCHK(dreads.alloc(len + 8));
+    HIPCHK(dpos.alloc(8 * total));
+    if (filled_init) {
+        HIPCHK(dfill.alloc(4 * n));
+        HIPCHK(hipMemcpy(dfill.p, filled_init, 4 * n, hipMemcpyHostToDevice));
+    }
+    if (len) HIPCHK(hipMemcpy(dreads.p, reads, len, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(dpos.p, 0, 8 * total));
+    HIPCHK(positions_fill(h->dev(), (const uint8_t*)dreads.p, len, first_shard ? a2_start(reads, len) : 0, (const uint64_t*)dind.p, (uint64_t*)dpos.p, piece,
+                          filled_init ? (const uint32_t*)dfill.p : nullptr, base_offset, 0));
     HIPCHK(hipMemcpy(positions_out, dpos.p, 8 * total, hipMemcpyDeviceToHost));
     return AIX_OK;
 }

@@ -41,7 +41,7 @@ hipError_t launch_coverage(const IndexDev& ix, const uint8_t* seqs, const uint64
 // index construction helpers
 hipError_t launch_build_keyrecs(const uint64_t* checker, const uint32_t* tf, uint64_t n, KeyRec* recs, uint32_t* noncanon_count, hipStream_t s);
 hipError_t launch_set_fingerprints(const MphfDev& m, BvRec* recs_rw, EeRec* ee_rw, const KeyRec* keys, uint64_t n, hipStream_t s);
-hipError_t launch_scatter23(const MphfDev& m, uint64_t n, const uint8_t* keys_ascii /* or */, const uint64_t* codes, const uint32_t* counts,
+hipError_t launch_scatter23(const MphfDev& m, uint64_t n, uint64_t nslots, const uint8_t* keys_ascii /* or */, const uint64_t* codes, const uint32_t* counts,
                             uint64_t* checker, uint32_t* tf, uint32_t* occupied_bits, uint32_t* conflict, hipStream_t s);
 hipError_t launch_perm13(const MphfDev& m, uint32_t* perm /* [4^13]: code -> mphf index */, hipStream_t s);
 hipError_t launch_tf13_to_code_order(const uint32_t* perm, const uint64_t* tf_mphf, uint64_t* tf_code, hipStream_t s);
@@ -63,7 +63,8 @@ hipError_t launch_gather(const uint8_t* table, uint64_t n_elems, int elem_bytes,
 // positions index (aix_positions.hip)
 hipError_t positions_indices(const IndexDev& ix, uint64_t* d_indices /* n+1 */, hipStream_t s);
 hipError_t positions_fill(const IndexDev& ix, const uint8_t* d_reads, uint64_t len, uint64_t start, const uint64_t* d_indices, uint64_t* d_positions,
-                          uint64_t piece, hipStream_t s);
+                          uint64_t piece, const uint32_t* filled_init, uint64_t base_offset, hipStream_t s);
+hipError_t positions_bucket_counts(const IndexDev& ix, const uint8_t* d_reads, uint64_t len, uint64_t start, unsigned long long* d_counts, hipStream_t s);
 
 // distinct k-mers = sort + run-length of window codes; outputs hipMalloc'd (caller frees), d_codes is clobbered
 hipError_t distinct_from_codes(uint64_t* d_codes, uint64_t nwin, int k, uint64_t min_count, uint64_t** d_keys_out, uint32_t** d_counts_out, uint64_t* n_out,

@@ -395,7 +395,7 @@ __global__ void __launch_bounds__(kBlock) k_set_fp(const MphfDev m, BvRec* __res
 // n x 23 ASCII bytes (the .dat lines) or as 2-bit codes. A slot hit twice raises `conflict`
 // (the reference detects it only when the earlier tf was non-zero, then exit(12)).
 template <bool ASCII>
-__global__ void __launch_bounds__(kBlock) k_scatter23(const MphfDev m, uint64_t n, const uint8_t* __restrict__ keys, const uint64_t* __restrict__ codes,
+__global__ void __launch_bounds__(kBlock) k_scatter23(const MphfDev m, uint64_t n, uint64_t nslots, const uint8_t* __restrict__ keys, const uint64_t* __restrict__ codes,
                                                      const uint32_t* __restrict__ counts, uint64_t* __restrict__ checker, uint32_t* __restrict__ tf,
                                                      uint32_t* __restrict__ occupied, uint32_t* __restrict__ conflict) {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
@@ -411,7 +411,7 @@ __global__ void __launch_bounds__(kBlock) k_scatter23(const MphfDev m, uint64_t 
         uint64_t a, b, c;
         jenkins23(w0, w1, w2, m.seed, a, b, c);
         const uint64_t h = mphf_from_hash(m, a, b, c);
-        if (h >= n) { atomicAdd(conflict, 1u); continue; }
+        if (h >= nslots) { atomicAdd(conflict, 1u); continue; }
         const uint32_t bit = 1u << (h & 31);
         if (atomicOr(&occupied[h >> 5], bit) & bit) { atomicAdd(conflict, 1u); continue; }
         checker[h] = code;
@@ -703,11 +703,11 @@ hipError_t launch_set_fingerprints(const MphfDev& m, BvRec* recs_rw, EeRec* ee_r
     hipLaunchKernelGGL(k_init_ee, dim3(grid_for(m.nrecs)), dim3(kBlock), 0, s, (const BvRec*)recs_rw, m.nrecs, ee_rw);
     AIX_LAUNCH(k_set_fp, n, s, m, recs_rw, ee_rw, keys, n);
 }
-hipError_t launch_scatter23(const MphfDev& m, uint64_t n, const uint8_t* keys, const uint64_t* codes, const uint32_t* counts, uint64_t* checker, uint32_t* tf,
+hipError_t launch_scatter23(const MphfDev& m, uint64_t n, uint64_t nslots, const uint8_t* keys, const uint64_t* codes, const uint32_t* counts, uint64_t* checker, uint32_t* tf,
                             uint32_t* occupied, uint32_t* conflict, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    if (keys) AIX_LAUNCH(k_scatter23<true>, n, s, m, n, keys, codes, counts, checker, tf, occupied, conflict);
-    AIX_LAUNCH(k_scatter23<false>, n, s, m, n, keys, codes, counts, checker, tf, occupied, conflict);
+    if (keys) AIX_LAUNCH(k_scatter23<true>, n, s, m, n, nslots, keys, codes, counts, checker, tf, occupied, conflict);
+    AIX_LAUNCH(k_scatter23<false>, n, s, m, n, nslots, keys, codes, counts, checker, tf, occupied, conflict);
 }
 hipError_t launch_perm13(const MphfDev& m, uint32_t* perm, hipStream_t s) { AIX_LAUNCH(k_perm13, 67108864ull, s, m, perm); }
 hipError_t launch_tf13_to_code_order(const uint32_t* perm, const uint64_t* tf_mphf, uint64_t* tf_code, hipStream_t s) {

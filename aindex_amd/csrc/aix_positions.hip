@@ -100,6 +100,15 @@ __global__ void __launch_bounds__(kB) k_a2_advance(const uint32_t* __restrict__ 
     }
 }
 
+// occurrences per bucket (u64, += ): the shard-local part of the reference's ppositions[h] counters
+__global__ void __launch_bounds__(kB) k_a2_tally(const uint32_t* __restrict__ keys, uint64_t nwin, uint32_t n, unsigned long long* __restrict__ counts) {
+    const uint64_t stride = (uint64_t)gridDim.x * kB;
+    for (uint64_t i = (uint64_t)blockIdx.x * kB + threadIdx.x; i < nwin; i += stride) {
+        const uint32_t h = keys[i];
+        if (h < n) atomicAdd(&counts[h], 1ull);
+    }
+}
+
 // indices (device, n+1 entries). Returns hip error.
 hipError_t positions_indices(const IndexDev& ix, uint64_t* d_indices, hipStream_t s) {
     const uint64_t n = ix.n;
@@ -121,8 +130,28 @@ hipError_t positions_indices(const IndexDev& ix, uint64_t* d_indices, hipStream_
 // positions (device, pre-zeroed, indices[n] entries) for a reads buffer in HBM. Windows are indexed with 32 bits inside a
 // piece; longer buffers go piece by piece in ascending order, the per-bucket fill counters carried from piece to piece, which
 // keeps every bucket's offsets ascending (the reference's 1-thread order) for any buffer length.
+// d_counts (device, u64[n], pre-zeroed): how often every bucket occurs in the buffer under A2's window rules
+hipError_t positions_bucket_counts(const IndexDev& ix, const uint8_t* d_reads, uint64_t len, uint64_t start, unsigned long long* d_counts, hipStream_t s) {
+    if (len < 23 || ix.n == 0) return hipSuccess;
+    const uint64_t nwin_all = len - 22;
+    const uint64_t pw = std::min<uint64_t>(1ull << 30, nwin_all);
+    uint32_t* keys = nullptr;
+    hipError_t e = hipMalloc((void**)&keys, 4 * pw);
+    for (uint64_t w0 = 0; e == hipSuccess && w0 < nwin_all; w0 += pw) {
+        const uint64_t nwin = std::min(pw, nwin_all - w0);
+        hipLaunchKernelGGL(k_a2_probe, dim3(grid_of(nwin)), dim3(kB), 0, s, ix, d_reads + w0, nwin, start > w0 ? start - w0 : 0, keys);
+        hipLaunchKernelGGL(k_a2_tally, dim3(grid_of(nwin)), dim3(kB), 0, s, keys, nwin, (uint32_t)ix.n, d_counts);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (keys) (void)hipFree(keys);
+    return e;
+}
+
+// filled_init (device, u32[n], may be null = zeros): occurrences of every bucket in the shards BEFORE this buffer;
+// base_offset: byte offset of this buffer inside the whole reads file (offsets are reported file-relative).
 hipError_t positions_fill(const IndexDev& ix, const uint8_t* d_reads, uint64_t len, uint64_t start, const uint64_t* d_indices, uint64_t* d_positions,
-                          uint64_t piece, hipStream_t s) {
+                          uint64_t piece, const uint32_t* filled_init, uint64_t base_offset, hipStream_t s) {
     if (len < 23 || ix.n == 0) return hipSuccess;
     const uint64_t nwin_all = len - 22;
     if (piece == 0 || piece > (1ull << 31)) piece = 1ull << 30;
@@ -134,7 +163,7 @@ hipError_t positions_fill(const IndexDev& ix, const uint8_t* d_reads, uint64_t l
     if (e == hipSuccess) e = hipMalloc((void**)&svals, 4 * pw);
     if (e == hipSuccess) e = hipMalloc((void**)&first, 4 * ix.n);
     if (e == hipSuccess) e = hipMalloc((void**)&filled, 4 * ix.n);
-    if (e == hipSuccess) e = hipMemsetAsync(filled, 0, 4 * ix.n, s);
+    if (e == hipSuccess) e = filled_init ? hipMemcpyAsync(filled, filled_init, 4 * ix.n, hipMemcpyDeviceToDevice, s) : hipMemsetAsync(filled, 0, 4 * ix.n, s);
     unsigned end_bit = 1;
     while (end_bit < 32 && (ix.n >> end_bit)) ++end_bit;                        // keys are in [0, n]
     size_t tmp_bytes = 0;
@@ -150,7 +179,7 @@ hipError_t positions_fill(const IndexDev& ix, const uint8_t* d_reads, uint64_t l
         if (e == hipSuccess) e = rocprim::radix_sort_pairs(tmp, tb, keys, skeys, iota, svals, (size_t)nwin, 0u, end_bit, s);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(k_a2_first, dim3(grid_of(nwin)), dim3(kB), 0, s, skeys, nwin, (uint32_t)ix.n, first);
-            hipLaunchKernelGGL(k_a2_place, dim3(grid_of(nwin)), dim3(kB), 0, s, ix, skeys, svals, nwin, w0, first, filled, d_indices, d_positions);
+            hipLaunchKernelGGL(k_a2_place, dim3(grid_of(nwin)), dim3(kB), 0, s, ix, skeys, svals, nwin, base_offset + w0, first, filled, d_indices, d_positions);
             if (w0 + pw < nwin_all) hipLaunchKernelGGL(k_a2_advance, dim3(grid_of(nwin)), dim3(kB), 0, s, skeys, nwin, (uint32_t)ix.n, first, filled);
             e = hipGetLastError();
         }

@@ -36,9 +36,15 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
 
 def shard_lines(buf: bytes, rank: int, world: int) -> bytes:
     """Record-aligned byte range of a PLAIN buffer (cuts only after '\\n'), contiguous per rank."""
+    lo, hi = shard_line_bounds(buf, rank, world)
+    return buf[lo:hi]
+
+
+def shard_line_bounds(buf: bytes, rank: int, world: int) -> Tuple[int, int]:
+    """[lo, hi) byte offsets of shard_lines(buf, rank, world)."""
     n = len(buf)
     if world == 1:
-        return buf
+        return 0, n
 
     def cut(pos):
         if pos <= 0:
@@ -49,7 +55,7 @@ def shard_lines(buf: bytes, rank: int, world: int) -> bytes:
         return n if j < 0 else j + 1
 
     lo, hi = shard_range(n, rank, world)
-    return buf[cut(lo):cut(hi)]
+    return cut(lo), cut(hi)
 
 
 def all_reduce_sum_(t):
@@ -187,3 +193,102 @@ def coverage_sharded(index, seqs, cutoff: int = 0):
     rank, world, _ = rank_world()
     lo, hi = shard_range(len(seqs), rank, world)
     return lo, hi, index.coverage(seqs[lo:hi], cutoff)
+
+
+# ---- I1 across ranks: every rank scatters a contiguous share of the key set, three all-reduces merge the shards -----
+def merge_scatter_shards(checker, tf, occupied):
+    """checker: int64 [n] (2-bit codes, zero where this rank wrote nothing), tf: int32 [n] (u32 bit patterns),
+    occupied: int32 [n] in {0, 1}. In place: checker = max over ranks (codes are < 2^46, i.e. non-negative), tf = sum,
+    occupied = sum. Returns True when two ranks wrote the same slot (the reference's collision, hash.cpp:703-709)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("AIX_FORCE_DIST")):
+        dist.all_reduce(checker, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tf, op=dist.ReduceOp.SUM)
+        dist.all_reduce(occupied, op=dist.ReduceOp.SUM)
+    return bool((occupied > 1).any().item())
+
+
+def scatter_sharded(pf_bytes: bytes, keys_u8, counts=None, device: int = 0):
+    """compute_index over ranks: `keys_u8` (n x 23 ASCII, the whole key set, same on every rank) is split into contiguous
+    ranges; every rank scatters its range through the MPHF on its GPU (aix_index_scatter_shard) and the shards are merged
+    with max / sum all-reduces. Returns (checker uint64[n], tf uint32[n]) on every rank; raises on any collision."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from ._lib import lib, vp, AIX_ERR_CONFLICT, check
+    rank, world, _ = rank_world()
+    keys = np.ascontiguousarray(keys_u8, dtype=np.uint8).reshape(-1, 23)
+    n = keys.shape[0]
+    lo, hi = shard_range(n, rank, world)
+    mine = np.ascontiguousarray(keys[lo:hi])
+    cnt = None if counts is None else np.ascontiguousarray(np.asarray(counts, dtype=np.uint32)[lo:hi])
+    checker = np.zeros(n, dtype=np.uint64)
+    tf = np.zeros(n, dtype=np.uint32)
+    occ = np.zeros((n + 31) // 32, dtype=np.uint32)
+    pf = np.frombuffer(pf_bytes, dtype=np.uint8)
+    st = lib().aix_index_scatter_shard(pf.ctypes.data_as(vp), pf.shape[0], mine.ctypes.data_as(vp), cnt.ctypes.data_as(vp) if cnt is not None else None,
+                                       hi - lo, n, device, checker.ctypes.data_as(vp), tf.ctypes.data_as(vp), occ.ctypes.data_as(vp))
+    if st != AIX_ERR_CONFLICT:
+        check(st, "aix_index_scatter_shard")
+    import torch.distributed as dist
+    on_gpu = dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
+    dev = f"cuda:{device}" if on_gpu else "cpu"
+    occ_bits = np.unpackbits(occ.view(np.uint8), bitorder="little")[:n].astype(np.int32)
+    ct = torch.from_numpy(checker.view(np.int64)).to(dev)
+    tt = torch.from_numpy(tf.view(np.int32)).to(dev)
+    ot = torch.from_numpy(occ_bits).to(dev)
+    bad = torch.tensor([1 if st == AIX_ERR_CONFLICT else 0], dtype=torch.int32, device=dev)
+    clash = merge_scatter_shards(ct, tt, ot)
+    all_reduce_sum_(bad)
+    if clash or int(bad.item()):
+        raise RuntimeError("hash conflict while scattering (a key outside the MPHF's key set, or a duplicate key)")
+    return ct.cpu().numpy().view(np.uint64), tt.cpu().numpy().view(np.uint32)
+
+
+# ---- A2 across ranks: buckets are global, so slots are resolved with per-rank bucket tallies (SURVEY 8e) ---------------
+def positions_fill_sharded(index, reads: bytes):
+    """compute_aindex over ranks: the reads file (same bytes on every rank) is cut after '\\n' into contiguous shards.
+    Pass 1: every rank tallies its windows per bucket; an all-gather gives each rank the occurrences in the shards before
+    it (the value the reference's ppositions counters would have when its single worker reaches this shard). Pass 2: every
+    rank fills its shard with slot numbering starting there; the disjoint partial arrays are summed.
+    Returns (indices uint64[n+1], positions uint64[sum tf]) on every rank == Index.positions_fill(reads)."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from ._lib import lib, check
+    rank, world, _ = rank_world()
+    active = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or bool(os.environ.get("AIX_FORCE_DIST")))
+    on_gpu = active and dist.get_backend() == "nccl"
+    dev = f"cuda:{index.device}" if on_gpu else "cpu"
+    lo, hi = shard_line_bounds(reads, rank, world)
+    mine = reads[lo:hi]
+    # the reference's start adjustment (hash.cpp:973-986) applies to the beginning of the FILE; it carries into the next
+    # shard when a shard has no clean window at all
+    st = C.c_uint64()
+    a = np.frombuffer(mine, dtype=np.uint8)
+    check(lib().aix_positions_start(a.ctypes.data_as(C.c_void_p) if a.shape[0] else None, a.shape[0], C.byref(st)), "aix_positions_start")
+    exhausted = 1 if (len(mine) < 23 or st.value >= len(mine) - 22) else 0
+    ex = torch.tensor([exhausted], dtype=torch.int32, device=dev)
+    exs = [torch.zeros(1, dtype=torch.int32, device=dev) for _ in range(world)]
+    if active and world > 1:
+        dist.all_gather(exs, ex)
+    else:
+        exs = [ex]
+    first = all(int(e.item()) == 1 for e in exs[:rank])
+    counts = torch.from_numpy(index.positions_bucket_counts(mine, first).view(np.int64)).to(dev)
+    if active and world > 1:
+        allc = [torch.empty_like(counts) for _ in range(world)]
+        dist.all_gather(allc, counts)
+    else:
+        allc = [counts]
+    before = torch.zeros_like(counts)
+    for r in range(rank):
+        before += allc[r]
+    filled = torch.clamp(before, max=(1 << 32) - 1).cpu().numpy().astype(np.uint32)
+    indices = index.positions_indices()
+    total = int(indices[-1])
+    part = index.positions_fill_shard(mine, total, first, lo, filled)
+    pt = torch.from_numpy(part.view(np.int64)).to(dev)
+    all_reduce_sum_(pt)                                   # every entry is written by exactly one rank
+    return indices, pt.cpu().numpy().view(np.uint64)

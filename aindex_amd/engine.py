@@ -251,6 +251,29 @@ class Index:
               "aix_positions_fill")
         return indices, pos
 
+    def positions_indices(self) -> np.ndarray:
+        """A1 alone: uint64[n+1] exclusive prefix sum of tf (the .indices.bin image)."""
+        indices = np.empty(self.n + 1, dtype=np.uint64)
+        total = C.c_uint64()
+        check(lib().aix_positions_fill(self._h, None, 0, _np_ptr(indices), None, 0, C.byref(total)), "aix_positions_fill")
+        return indices
+
+    def positions_bucket_counts(self, reads: bytes, first_shard: bool = True) -> np.ndarray:
+        """uint64[n]: windows of `reads` per bucket under A2's rules (the shard-local ppositions counters)."""
+        a = np.frombuffer(reads, dtype=np.uint8)
+        out = np.zeros(self.n, dtype=np.uint64)
+        check(lib().aix_positions_bucket_counts(self._h, _np_ptr(a), a.shape[0], int(first_shard), _np_ptr(out)), "aix_positions_bucket_counts")
+        return out
+
+    def positions_fill_shard(self, reads: bytes, total: int, first_shard: bool, base_offset: int, filled_init: Optional[np.ndarray]) -> np.ndarray:
+        """uint64[total]: this shard's entries of the positions array (zero elsewhere); see aix_positions_fill_shard."""
+        a = np.frombuffer(reads, dtype=np.uint8)
+        pos = np.zeros(total, dtype=np.uint64)
+        f = None if filled_init is None else np.ascontiguousarray(filled_init, dtype=np.uint32)
+        check(lib().aix_positions_fill_shard(self._h, _np_ptr(a), a.shape[0], int(first_shard), base_offset, _np_ptr(f), _np_ptr(pos), pos.shape[0]),
+              "aix_positions_fill_shard")
+        return pos
+
     # ---- HBM-resident (torch) entry points: asynchronous on torch's current stream ------------
     def _chk_dev(self, t):
         if not t.is_cuda or t.device.index != self.device:

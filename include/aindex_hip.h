@@ -104,6 +104,12 @@ int aix_index_get_checker(const aix_index_t* h, uint64_t* out, uint64_t n);
  * AIX_ERR_CONFLICT when two keys land in one slot or a slot >= n (reference: exit(12) / OOB write). */
 int aix_index_scatter(const void* pf_bytes, uint64_t pf_len, const char* keys, const uint32_t* counts, uint64_t n,
                       int device, uint64_t* checker_out, uint32_t* tf_out);
+/* the same for a SHARD of the key set (multi-GPU index construction): n_keys keys scatter into full-size
+ * arrays of n_slots entries (zero where this shard wrote nothing); occupied_out = ceil(n_slots/32) words, bit h set
+ * <=> slot h was written. The caller merges shards with sum(tf), max(checker) and detects cross-shard collisions as
+ * overlapping occupied bits. AIX_ERR_CONFLICT (collision inside the shard) still fills the outputs. */
+int aix_index_scatter_shard(const void* pf_bytes, uint64_t pf_len, const char* keys, const uint32_t* counts, uint64_t n_keys,
+                            uint64_t n_slots, int device, uint64_t* checker_out, uint32_t* tf_out, uint32_t* occupied_out);
 /* the same scatter from 2-bit codes already in HBM, keeping the result resident as a 23-mer handle */
 int aix_index_build_23_codes_dev(const void* pf_bytes, uint64_t pf_len, const uint64_t* d_codes,
                                  const uint32_t* d_counts /* nullable */, uint64_t n, int device, void* stream,
@@ -194,6 +200,19 @@ int aix_window_codes_dev(const char* d_plain, uint64_t len, int k, int canon_mod
  * Any length: buffers of more than 2^30 windows are filled piece by piece, per-bucket fill counters carried over. */
 int aix_positions_fill(aix_index_t* h, const char* reads, uint64_t len, uint64_t* indices_out, uint64_t* positions_out,
                        uint64_t positions_cap, uint64_t* total_out);
+/* A2 over SHARDS of the reads file (multi-GPU). Shards are cut after '\n' (no window spans a cut).
+ * aix_positions_bucket_counts: counts_out[h] (u64[n]) = windows of this shard that fall into bucket h under A2's rules;
+ * aix_positions_fill_shard: the fill of this shard alone, with bucket h's slot numbering starting at filled_init[h]
+ * (= occurrences in all EARLIER shards, clamped to 2^32-1; NULL = zeros) and offsets reported as base_offset + local
+ * offset + 1. positions_out is the FULL-size array (indices[n] entries); entries this shard does not own are zero, so
+ * the shards combine by addition. first_shard != 0 applies the reference's start adjustment (hash.cpp:973-986), which
+ * only the beginning of the file sees. The union over shards equals aix_positions_fill of the whole file. */
+int aix_positions_bucket_counts(aix_index_t* h, const char* reads, uint64_t len, int first_shard, uint64_t* counts_out);
+/* the start adjustment itself (host only): first window offset the reference's single worker looks at. A shard whose
+ * adjusted start is >= its window count has no clean window, and the adjustment carries on into the next shard. */
+int aix_positions_start(const char* reads, uint64_t len, uint64_t* start_out);
+int aix_positions_fill_shard(aix_index_t* h, const char* reads, uint64_t len, int first_shard, uint64_t base_offset,
+                             const uint32_t* filled_init, uint64_t* positions_out, uint64_t positions_cap);
 /* K1 complete: replaces `kmer_counter <in.fa> <k> <out> [-t N] [-m min]` (src/count_kmers.cpp:235-382): the set of
  * (canonical k-mer code, count) with count >= min_count, sorted by code ascending (the reference sorts by count with
  * unspecified tie order; parity is on the set). *keys_out / *counts_out are malloc'd (aix_free). format as for the

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as O                                    # noqa: E402
-from aindex_amd import _lib, dist as adist       # noqa: E402
+from aindex_amd import _lib, dist as adist, synth       # noqa: E402
 from aindex_amd.engine import Index                        # noqa: E402
 
 
@@ -45,6 +45,18 @@ def main():
         lo, hi, prof = adist.coverage_sharded(ix, seqs, 2)
         for s, p in zip(seqs[lo:hi], prof):
             assert np.array_equal(p, orc.coverage(s, 2))
+        # A2 across ranks: bucket tallies -> all-gather -> shard fills with carried slot numbering -> sum == the reference's
+        # 1-thread files; then a buffer whose first shard has no clean window, so that the start adjustment carries over
+        z = np.load(os.path.join(ROOT, "tests", "golden", "small23", "aindex.npz"))
+        ind, pos = adist.positions_fill_sharded(ix, reads)
+        assert np.array_equal(ind, z["indices"]) and np.array_equal(pos, z["index"])
+        lines = [l for l in reads.split(b"\n") if l]
+        tricky = b"ACGTAC\n" * 2500 + lines[0][:30] + b"?" + lines[0][31:] + b"\n" + b"\n".join(lines[:40] + lines[:25]) + b"\n"
+        want_ind, want_pos = orc.positions(tricky)
+        ind, pos = adist.positions_fill_sharded(ix, tricky)
+        assert np.array_equal(ind, want_ind) and np.array_equal(pos, want_pos) and (pos != 0).sum() > 1000
+        i1, p1 = ix.positions_fill(tricky)
+        assert np.array_equal(p1, want_pos)
         cnt = torch.tensor([hi - lo], dtype=torch.int64, device="cuda:0" if dist.get_backend() == "nccl" else "cpu")
         adist.all_reduce_sum_(cnt)
         assert int(cnt.item()) == len(seqs)
@@ -58,6 +70,19 @@ def main():
         o = np.argsort(allk, kind="stable")
         fk, fc = O.count_distinct(fasta, k, mode, minc)
         assert fk.shape[0] > 100 and np.array_equal(allk[o], fk) and np.array_equal(allc[o], fc.astype(np.uint64)), (k, mode, minc)
+    # I1 across ranks: shard scatter on the GPU + max/sum merges == the reference's compute_index files
+    full_checker = np.fromfile(prefix + ".kmers.bin", dtype=np.uint64)
+    full_tf = np.fromfile(prefix + ".tf.bin", dtype=np.uint32)
+    perm = np.random.default_rng(3).permutation(full_checker.shape[0])
+    keys = synth.decode_kmers(full_checker, 23)[perm]
+    ck, tfv = adist.scatter_sharded(open(prefix + ".pf", "rb").read(), keys, full_tf[perm], device=0)
+    assert np.array_equal(ck, full_checker) and np.array_equal(tfv, full_tf)
+    bad = keys.copy(); bad[-1] = bad[0]                                   # a duplicate key: collision, reported on every rank
+    try:
+        adist.scatter_sharded(open(prefix + ".pf", "rb").read(), bad, full_tf[perm], device=0)
+        raise AssertionError("duplicate key not detected")
+    except RuntimeError as e:
+        assert "conflict" in str(e)
     from pf13 import pf13_path
     with Index.open_13(pf13_path(), None, device=0) as ix13:
         got = adist.count13_sharded(ix13, plain, device=0).cpu().numpy().view(np.uint64)

@@ -71,6 +71,24 @@ def main():
         o = np.argsort(allk, kind="stable")
         fk, fc = O.count_distinct(fasta(lines), k, mode, minc)
         assert fk.shape[0] > 100 and np.array_equal(allk[o], fk) and np.array_equal(allc[o], fc.astype(np.uint64)), (k, mode, minc)
+    # I1 across ranks: every rank scatters a contiguous share of the keys into zeroed full-size arrays (slots from the
+    # oracle MPHF here), merge = max(checker) / sum(tf) / sum(occupied); == the golden .kmers.bin / .tf.bin
+    m = O.OracleMphf(prefix + ".pf")
+    full_checker = np.fromfile(prefix + ".kmers.bin", dtype=np.uint64)
+    full_tf = np.fromfile(prefix + ".tf.bin", dtype=np.uint32)
+    keys = synth.decode_kmers(full_checker, 23)
+    perm = np.random.default_rng(3).permutation(keys.shape[0])      # .dat order is not slot order
+    keys, cnts = keys[perm], full_tf[perm]
+    lo, hi = adist.shard_range(keys.shape[0], rank, world)
+    slots = np.array([m.lookup(bytes(x)) for x in keys[lo:hi]], dtype=np.int64)
+    ck = np.zeros(orc.n, dtype=np.int64); tfp = np.zeros(orc.n, dtype=np.int32); oc = np.zeros(orc.n, dtype=np.int32)
+    ck[slots] = synth.encode_kmers(keys[lo:hi]).view(np.int64); tfp[slots] = cnts[lo:hi].view(np.int32); oc[slots] = 1
+    ckt, tft, oct_ = torch.from_numpy(ck), torch.from_numpy(tfp), torch.from_numpy(oc)
+    assert adist.merge_scatter_shards(ckt, tft, oct_) is False
+    assert np.array_equal(ckt.numpy().view(np.uint64), full_checker) and np.array_equal(tft.numpy().view(np.uint32), full_tf)
+    assert int(oct_.sum()) == orc.n
+    dup = torch.zeros(orc.n, dtype=torch.int32); dup[0] = 1         # both ranks claim slot 0 -> collision reported on every rank
+    assert adist.merge_scatter_shards(torch.zeros(orc.n, dtype=torch.int64), torch.zeros(orc.n, dtype=torch.int32), dup) is True
     t = adist.all_reduce_max_float(float(rank + 1))
     assert t == 2.0
     adist.barrier()

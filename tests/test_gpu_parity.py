@@ -101,6 +101,34 @@ def test_index_scatter_equals_compute_index(small23_prefix):
     assert st in (0, -12)   # lands on a free slot only if it happens to hash onto its victim's slot
 
 
+def test_index_scatter_shards_merge_to_whole(small23_prefix):
+    """aix_index_scatter_shard: three uneven shards of the key set into full-size arrays; sum / max / OR == one scatter
+    == the reference's files; a shard with an internal duplicate reports AIX_ERR_CONFLICT and still returns its arrays."""
+    from aindex_amd._lib import lib, vp, AIX_ERR_CONFLICT
+    pf = np.fromfile(small23_prefix + ".pf", dtype=np.uint8)
+    checker = np.fromfile(small23_prefix + ".kmers.bin", dtype=np.uint64)
+    tf = np.fromfile(small23_prefix + ".tf.bin", dtype=np.uint32)
+    n = checker.shape[0]
+    perm = np.random.default_rng(9).permutation(n)
+    keys, cnts = synth.decode_kmers(checker, 23)[perm], tf[perm]
+    acc_c, acc_t, acc_o = np.zeros(n, np.uint64), np.zeros(n, np.uint32), np.zeros((n + 31) // 32, np.uint32)
+    for lo, hi in ((0, 1), (1, n // 3), (n // 3, n), (n, n)):
+        k = np.ascontiguousarray(keys[lo:hi]); c = np.ascontiguousarray(cnts[lo:hi])
+        oc, ot, oo = np.empty(n, np.uint64), np.empty(n, np.uint32), np.empty((n + 31) // 32, np.uint32)
+        st = lib().aix_index_scatter_shard(pf.ctypes.data_as(vp), pf.shape[0], k.ctypes.data_as(vp), c.ctypes.data_as(vp), hi - lo, n, 0,
+                                           oc.ctypes.data_as(vp), ot.ctypes.data_as(vp), oo.ctypes.data_as(vp))
+        assert st == 0
+        assert int(np.unpackbits(oo.view(np.uint8)).sum()) == hi - lo and not np.any(acc_o & oo)
+        acc_c = np.maximum(acc_c, oc); acc_t += ot; acc_o |= oo
+    assert np.array_equal(acc_c, checker) and np.array_equal(acc_t, tf)
+    assert int(np.unpackbits(acc_o.view(np.uint8)).sum()) == n
+    k = np.ascontiguousarray(np.concatenate([keys[:5], keys[:1]]))
+    oc, ot, oo = np.empty(n, np.uint64), np.empty(n, np.uint32), np.empty((n + 31) // 32, np.uint32)
+    st = lib().aix_index_scatter_shard(pf.ctypes.data_as(vp), pf.shape[0], k.ctypes.data_as(vp), None, 6, n, 0,
+                                       oc.ctypes.data_as(vp), ot.ctypes.data_as(vp), oo.ctypes.data_as(vp))
+    assert st == AIX_ERR_CONFLICT and int(np.unpackbits(oo.view(np.uint8)).sum()) == 5 and not ot.any()      # mock mode: tf stays 0
+
+
 def test_count23_fixed_refx86_equals_pipeline(ix23, gold, small23_prefix):
     fa = open(os.path.join(gold, "small23", "reads.fa"), "rb").read()
     tf = ix23.count23_fixed(fa, _lib.FMT_FASTA, _lib.CANON_REF_X86)
@@ -414,6 +442,51 @@ def test_positions_fill_in_pieces(ix23, gold, small23_prefix, canon_case, piece)
             assert np.array_equal(indices, want_ind) and np.array_equal(pos, want_pos)
     finally:
         del os.environ["AIX_POSITIONS_PIECE"]
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_positions_fill_shards_equal_whole(canon_case, world):
+    """The two-pass shard protocol of dist.positions_fill_sharded, run rank by rank in one process: per-shard bucket
+    tallies, exclusive sum over earlier shards, shard fills into full-size arrays, sum == the unsharded fill == oracle.
+    The buffer starts with a stretch without any clean window (the start adjustment carries into later shards), holds
+    '?' right after it, lower-case reads, PE separators and repeated reads that overflow their buckets."""
+    import ctypes as C
+    from aindex_amd import dist as adist
+    from aindex_amd._lib import lib, vp
+    ix, orc = canon_case["ix"], canon_case["orc"]
+    asc = synth.genome_ascii(23, 300_000)
+    r = synth.reads_plain(45, asc, 600, 150, rc_fraction_half=True, n_rate_ppm=2000).reshape(-1, 151).copy()
+    r[::7, 150] = ord("~")
+    r[3::40] |= 0x20
+    r[3::40, 150] = ord("\n")
+    r[0, 5] = ord("?")
+    body = r.tobytes() + r[:300].tobytes()
+    for lead in (b"", b"ACGTAC\n" * (2 * len(body) // 7), b"?AC\n"):
+        buf = lead + body
+        want_ind, want_pos = orc.positions(buf)
+        assert np.array_equal(ix.positions_fill(buf)[1], want_pos)
+        bounds = [adist.shard_line_bounds(buf, k, world) for k in range(world)]
+        assert bounds[0][0] == 0 and bounds[-1][1] == len(buf) and all(bounds[k][1] == bounds[k + 1][0] for k in range(world - 1))
+        first, tallies = [], []
+        all_exhausted = True
+        for lo, hi in bounds:
+            a = np.frombuffer(buf[lo:hi], dtype=np.uint8)
+            st = C.c_uint64()
+            assert lib().aix_positions_start(a.ctypes.data_as(vp) if a.shape[0] else None, a.shape[0], C.byref(st)) == 0
+            first.append(all_exhausted)
+            all_exhausted = all_exhausted and (hi - lo < 23 or st.value >= hi - lo - 22)
+            tallies.append(ix.positions_bucket_counts(buf[lo:hi], first[-1]))
+        total = int(want_ind[-1])
+        acc = np.zeros(total, dtype=np.uint64)
+        before = np.zeros(ix.n, dtype=np.uint64)
+        for (lo, hi), f, t in zip(bounds, first, tallies):
+            part = ix.positions_fill_shard(buf[lo:hi], total, f, lo, np.minimum(before, 2 ** 32 - 1).astype(np.uint32))
+            assert not np.any((acc != 0) & (part != 0))                   # every slot has one owner
+            acc += part
+            before += t
+        assert np.array_equal(ix.positions_indices(), want_ind) and np.array_equal(acc, want_pos), (world, len(lead))
+        if lead.startswith(b"ACGTAC"):
+            assert first[1] is True                                       # the adjustment did carry into the second shard
 
 
 @pytest.mark.slow
