@@ -23,21 +23,41 @@ static constexpr int C13_BINS = 1 << C13_BINBITS;     // 32768 bins per partitio
 static constexpr int C13_TB = 1024;                   // threads per workgroup
 static constexpr int C13_WPT = 32;                    // window starts per lane
 static constexpr int C13_TILE = C13_TB * C13_WPT;     // 32768 window starts per tile
+static constexpr int C13_DUMMY = 64;                  // scratch histogram bins for windows that do not count
 
-// Encode the C13_WPT windows whose starts are [S, S+WPT): code[j] (26 bits) and a validity bit mask.
+// Encode the C13_WPT windows whose starts are [S, S+WPT): the packed 2-bit stream (Run13::code<j>() = 26 bits) and a validity bit mask.
 // Bytes at positions >= len count as separators. Upper-casing and the ACGT test follow
 // normalize_sequence / is_valid_kmer (count_kmers13.cpp:100-126).
-__device__ __forceinline__ uint32_t encode_run13(const uint8_t* __restrict__ buf, uint64_t len, uint64_t S, uint32_t (&code)[C13_WPT]) {
+struct Run13 {
+    uint32_t w[3];        // 2-bit stream of the 44 bytes, base 0 in the top bits of w[0]; w[2] holds bases 32..43 in its top 24 bits
+    uint32_t valid;       // bit j: window j (bytes j..j+12) consists of bases only
+    // 26-bit code of window j = stream bits [70 - 2j, 95 - 2j] of the 96-bit big-endian stream {w0, w1, w2}; two VALU
+    // operations, so the windows are re-extracted where they are needed instead of being kept in 32 registers
+    template <int J>
+    __device__ __forceinline__ uint32_t code() const {
+        constexpr int sh = 70 - 2 * J;
+        uint32_t c;
+        if (sh >= 64) c = w[0] >> (sh - 64);
+        else if (sh >= 32) c = __funnelshift_r(w[1], w[0], sh - 32);
+        else c = __funnelshift_r(w[2], w[1], sh);
+        return c & 0x3FFFFFFu;
+    }
+};
+template <int J, typename F>
+__device__ __forceinline__ void for_each_window13(const Run13& r, F&& f) {
+    if constexpr (J < C13_WPT) {
+        f(J, r.template code<J>(), (r.valid >> J) & 1u);
+        for_each_window13<J + 1>(r, f);
+    }
+}
+
+__device__ __forceinline__ Run13 encode_run13(const uint8_t* __restrict__ buf, uint64_t len, uint64_t S) {
     constexpr int NB = C13_WPT + 12;                  // 44 bytes
     constexpr int ND = NB / 4;                        // 11 aligned dwords
-    uint32_t e[ND];
-    uint32_t validmask = 0;
-    if (S >= len) {
-#pragma unroll
-        for (int j = 0; j < C13_WPT; ++j) code[j] = 0;
-        return 0;
-    }
+    Run13 r{{0, 0, 0}, 0};
+    if (S >= len) return r;
     const uint64_t limit = len - S;                   // bytes available from S
+    uint32_t e[ND];
     {
         const uint32_t o = (uint32_t)((uintptr_t)(buf + S) & 3);
         const uint32_t* q = (const uint32_t*)(buf + S - o);           // pointer arithmetic keeps these global_load (not flat_load)
@@ -49,33 +69,38 @@ __device__ __forceinline__ uint32_t encode_run13(const uint8_t* __restrict__ buf
 #pragma unroll
         for (int k = 0; k < ND; ++k) e[k] = __funnelshift_r(d[k], d[k + 1], sh);
     }
-    uint32_t c26 = 0, run = 0;
+    // Four bytes at a time (the VALU issues one wave instruction per clock per CU, and the byte-serial form of this loop
+    // was ~2/3 of the kernel): x = upper-cased bytes; v = 2-bit value of every byte; a byte is a base iff it equals the
+    // letter its own 2-bit value maps back to (v_perm_b32 as the 4-entry table); q = the four values packed first-base-high.
+    uint64_t vmask = 0;                               // bit i: byte i is A/C/G/T (either case)
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        const uint32_t c = (e[i >> 2] >> (8 * (i & 3))) & 0xDFu;
-        const uint32_t v = ((c >> 1) ^ (c >> 2)) & 3u;
-        const bool ok = (c == ((AIX_LUT_ACGT >> (8 * v)) & 0xFFu)) && ((uint64_t)i < limit);
-        c26 = ((c26 << 2) | v) & 0x3FFFFFFu;
-        run = ok ? run + 1 : 0;
-        if (i >= 12) {
-            code[i - 12] = c26;
-            if (run >= 13) validmask |= 1u << (i - 12);
-        }
+    for (int k = 0; k < ND; ++k) {
+        const uint32_t x = e[k] & 0xDFDFDFDFu;
+        const uint32_t v = ((x >> 1) ^ (x >> 2)) & 0x03030303u;
+        const uint32_t diff = x ^ lut4(v, AIX_LUT_ACGT);
+        const uint32_t z = ~(((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff | 0x7F7F7F7Fu);      // 0x80 in every byte where diff == 0
+        const uint32_t f = z >> 7;
+        const uint32_t nib = (f | (f >> 7) | (f >> 14) | (f >> 21)) & 0xFu;
+        const uint32_t q = ((v << 6) & 0xC0u) | ((v >> 4) & 0x30u) | ((v >> 14) & 0x0Cu) | (v >> 24);
+        r.w[k >> 2] |= q << (24 - 8 * (k & 3));
+        vmask |= (uint64_t)nib << (4 * k);
     }
-    return validmask;
+    if (limit < (uint64_t)NB) vmask &= (1ull << limit) - 1;           // bytes at and past the end of the buffer are separators
+    // window j (bytes j..j+12) is countable iff 13 consecutive mask bits are set
+    const uint64_t m2 = vmask & (vmask >> 1), m4 = m2 & (m2 >> 2), m8 = m4 & (m4 >> 4);
+    r.valid = (uint32_t)(m8 & (m4 >> 8) & (vmask >> 12));
+    return r;
 }
 
 // P1: per-(workgroup, partition) window counts. Workgroup b owns tiles b, b+G, b+2G, ... in P1 and in P2 alike.
 __global__ void __launch_bounds__(C13_TB) k_c13_sizes(const uint8_t* __restrict__ buf, uint64_t len, uint64_t ntiles, uint32_t* __restrict__ cnt /* [G][P] */) {
-    __shared__ uint32_t hist[C13_P];
-    for (int i = threadIdx.x; i < C13_P; i += C13_TB) hist[i] = 0;
+    __shared__ uint32_t hist[C13_P + C13_DUMMY];      // windows that do not count go to one of 64 scratch bins (no branch per window)
+    for (int i = threadIdx.x; i < C13_P + C13_DUMMY; i += C13_TB) hist[i] = 0;
     __syncthreads();
     for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        uint32_t code[C13_WPT];
-        const uint32_t vm = encode_run13(buf, len, t * C13_TILE + (uint64_t)threadIdx.x * C13_WPT, code);
-#pragma unroll
-        for (int j = 0; j < C13_WPT; ++j)
-            if (vm & (1u << j)) atomicAdd(&hist[code[j] >> C13_BINBITS], 1u);
+        const Run13 run = encode_run13(buf, len, t * C13_TILE + (uint64_t)threadIdx.x * C13_WPT);
+        const uint32_t dummy = C13_P + (threadIdx.x & (C13_DUMMY - 1));
+        for_each_window13<0>(run, [&](int, uint32_t code, uint32_t ok) { atomicAdd(&hist[ok ? code >> C13_BINBITS : dummy], 1u); });
     }
     __syncthreads();
     uint32_t* row = cnt + (uint64_t)blockIdx.x * C13_P;
@@ -124,7 +149,7 @@ __global__ void __launch_bounds__(C13_TB) k_c13_split(const uint8_t* __restrict_
                                                      const uint32_t* __restrict__ cnt /* [G][P] exclusive over workgroups */, uint16_t* __restrict__ parts) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t* hist = (uint32_t*)smem;                           // [P] tile-local count per partition
-    uint32_t* loc_off = hist + C13_P;                           // [P] exclusive scan of hist
+    uint32_t* loc_off = hist + C13_P + C13_DUMMY;               // [P] exclusive scan of hist (hist has C13_DUMMY scratch bins behind it)
     uint32_t* cursor = loc_off + C13_P;                         // [P] next free slot of this workgroup's segment (absolute)
     uint32_t* wsum = cursor + C13_P;                            // [16]
     uint32_t* sorted = wsum + 16;                               // [TILE] (partition << 16) | low 15 bits, grouped by partition
@@ -135,18 +160,17 @@ __global__ void __launch_bounds__(C13_TB) k_c13_split(const uint8_t* __restrict_
         cursor[2 * t + 1] = (uint32_t)part_base[2 * t + 1] + row[2 * t + 1];
         hist[2 * t] = 0;
         hist[2 * t + 1] = 0;
+        if (t < C13_DUMMY) hist[C13_P + t] = 0;
     }
     __syncthreads();
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        uint32_t code[C13_WPT];
         uint32_t rank[C13_WPT / 2];                              // two 16-bit ranks per register
-        const uint32_t vm = encode_run13(buf, len, tile * C13_TILE + (uint64_t)t * C13_WPT, code);
-#pragma unroll
-        for (int j = 0; j < C13_WPT; ++j) {
-            uint32_t r = 0;
-            if (vm & (1u << j)) r = atomicAdd(&hist[code[j] >> C13_BINBITS], 1u);
+        const Run13 run = encode_run13(buf, len, tile * C13_TILE + (uint64_t)t * C13_WPT);
+        const uint32_t dummy = C13_P + (t & (C13_DUMMY - 1));    // windows that do not count take a rank from a scratch bin: no branch
+        for_each_window13<0>(run, [&](int j, uint32_t code, uint32_t ok) {
+            const uint32_t r = atomicAdd(&hist[ok ? code >> C13_BINBITS : dummy], 1u);   // < 2^16 (scratch bins: <= 512 per tile)
             if (j & 1) rank[j >> 1] |= r << 16; else rank[j >> 1] = r;
-        }
+        });
         __syncthreads();
         const uint32_t a = hist[2 * t], b = hist[2 * t + 1];
         {   // exclusive scan of hist[2048]
@@ -165,14 +189,13 @@ __global__ void __launch_bounds__(C13_TB) k_c13_split(const uint8_t* __restrict_
             loc_off[2 * t + 1] = excl + a;
         }
         __syncthreads();
-#pragma unroll
-        for (int j = 0; j < C13_WPT; ++j) {
-            if (vm & (1u << j)) {
-                const uint32_t p = code[j] >> C13_BINBITS;
+        for_each_window13<0>(run, [&](int j, uint32_t code, uint32_t ok) {
+            if (ok) {
+                const uint32_t p = code >> C13_BINBITS;
                 const uint32_t r = (j & 1) ? (rank[j >> 1] >> 16) : (rank[j >> 1] & 0xFFFFu);
-                sorted[loc_off[p] + r] = (p << 16) | (code[j] & (C13_BINS - 1));
+                sorted[loc_off[p] + r] = (p << 16) | (code & (C13_BINS - 1));
             }
-        }
+        });
         __syncthreads();
         const uint32_t total = loc_off[C13_P - 1] + hist[C13_P - 1];
         for (uint32_t i = t; i < total; i += C13_TB) {
@@ -185,6 +208,7 @@ __global__ void __launch_bounds__(C13_TB) k_c13_split(const uint8_t* __restrict_
         cursor[2 * t + 1] += b;
         hist[2 * t] = 0;
         hist[2 * t + 1] = 0;
+        if (t < C13_DUMMY) hist[C13_P + t] = 0;
         __syncthreads();
     }
 }
@@ -257,7 +281,7 @@ hipError_t launch_count13_partitioned(const uint8_t* buf, uint64_t len, void* wo
     const uint64_t ntiles = (nwin + C13_TILE - 1) / C13_TILE;
     const unsigned grid = (unsigned)std::min<uint64_t>(ntiles ? ntiles : 1, C13_MAXGRID);
     const size_t hist_lds = 4 * C13_BINS;                                   // 131 072 B
-    const size_t split_lds = 4 * (3 * C13_P + 16) + 4 * C13_TILE;           // 155 712 B
+    const size_t split_lds = 4 * (3 * C13_P + C13_DUMMY + 16) + 4 * C13_TILE;   // 155 968 B
     {   // > 64 KiB of dynamic LDS needs the attribute; set per call (cheap, and correct for every device / thread)
         hipError_t e = hipFuncSetAttribute((const void*)k_c13_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds);
         if (e != hipSuccess) return e;
