@@ -80,6 +80,8 @@ SIGNATURES = {
     "aix_count23_fixed_dev": (i32, [vp, vp, u64, i32, vp, vp]),
     "aix_count_distinct": (i32, [vp, u64, i32, i32, i32, u64, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]),
     "aix_positions_fill": (i32, [vp, vp, u64, vp, vp, u64, C.POINTER(u64)]),
+    "aix_positions_total": (i32, [vp, C.POINTER(u64)]),
+    "aix_positions_fill_dev": (i32, [vp, vp, u64, u64, vp, vp, u64, vp]),
     "aix_positions_bucket_counts": (i32, [vp, vp, u64, i32, vp]),
     "aix_positions_start": (i32, [vp, u64, C.POINTER(u64)]),
     "aix_positions_fill_shard": (i32, [vp, vp, u64, i32, u64, vp, vp, u64]),

@@ -984,6 +984,43 @@ extern "C" int aix_positions_fill(aix_index_t* h, const char* reads, uint64_t le
     return AIX_OK;
 }
 
+// device-resident twin: reads already in HBM, indices (n+1) and positions (indices[n], caller-sized through
+// aix_positions_total) written in HBM. `start` = aix_positions_start of the buffer's head (the caller holds the bytes).
+extern "C" int aix_positions_total(aix_index_t* h, uint64_t* total_out) {
+    if (!h || !total_out) return AIX_ERR_ARG;
+    if (h->k != 23) return AIX_ERR_MODE;
+    DevGuard g(h->device);
+    *total_out = 0;
+    if (h->n == 0) return AIX_OK;
+    DevBuf dind;
+    HIPCHK(dind.alloc(8 * (h->n + 1)));
+    HIPCHK(positions_indices(h->dev(), (uint64_t*)dind.p, 0));
+    HIPCHK(hipMemcpy(total_out, (const uint64_t*)dind.p + h->n, 8, hipMemcpyDeviceToHost));
+    return AIX_OK;
+}
+
+extern "C" int aix_positions_fill_dev(aix_index_t* h, const char* d_reads, uint64_t len, uint64_t start, uint64_t* d_indices_out, uint64_t* d_positions_out,
+                                      uint64_t positions_cap, void* stream) {
+    if (!h || !d_indices_out || (len && !d_reads)) return AIX_ERR_ARG;
+    if (h->k != 23) return AIX_ERR_MODE;
+    DevGuard g(h->device);
+    hipStream_t s = (hipStream_t)stream;
+    const uint64_t n = h->n;
+    uint64_t piece = 0;
+    if (const char* e = getenv("AIX_POSITIONS_PIECE")) piece = strtoull(e, nullptr, 10);
+    if (n) HIPCHK(positions_indices(h->dev(), d_indices_out, s));           // synchronises the stream
+    else HIPCHK(hipMemsetAsync(d_indices_out, 0, 8, s));
+    if (n == 0) return AIX_OK;
+    uint64_t total = 0;
+    HIPCHK(hipMemcpyAsync(&total, d_indices_out + n, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (total == 0) return AIX_OK;
+    if (!d_positions_out || positions_cap < total) return AIX_ERR_ARG;
+    HIPCHK(hipMemsetAsync(d_positions_out, 0, 8 * total, s));
+    HIPCHK(positions_fill(h->dev(), (const uint8_t*)d_reads, len, start, d_indices_out, d_positions_out, piece, nullptr, 0, s));
+    return AIX_OK;
+}
+
 extern "C" int aix_positions_start(const char* reads, uint64_t len, uint64_t* start_out) {
     if (!start_out || (len && !reads)) return AIX_ERR_ARG;
     *start_out = a2_start(reads, len);

@@ -330,6 +330,29 @@ class Index:
                                            vp(out_t.data_ptr()), vp(out_offs_t.data_ptr()), _stream_ptr()), "aix_coverage_batch_dev")
         return out_t
 
+    def positions_fill_t(self, reads_t):
+        """A1 + A2 with the reads buffer already in HBM: (indices int64[n+1], positions int64[sum tf]) device tensors
+        holding the u64 bit patterns of the .indices.bin / .index.bin images."""
+        import torch
+        self._chk_dev(reads_t)
+        total = C.c_uint64()
+        check(lib().aix_positions_total(self._h, C.byref(total)), "aix_positions_total")
+        # the reference's start adjustment looks at the head of the buffer (hash.cpp:973-986); fetch as much of it as needed
+        head_len, start = 1 << 16, C.c_uint64()
+        while True:
+            head = reads_t[:head_len].cpu().numpy()
+            check(lib().aix_positions_start(_np_ptr(head), head.shape[0], C.byref(start)), "aix_positions_start")
+            if head.shape[0] == reads_t.numel() or start.value + 64 < head.shape[0]:
+                break
+            head_len *= 16
+        dev = reads_t.device
+        indices = torch.empty(self.n + 1, dtype=torch.int64, device=dev)
+        pos = torch.empty(max(total.value, 1), dtype=torch.int64, device=dev)[: total.value]
+        with torch.cuda.device(dev):
+            check(lib().aix_positions_fill_dev(self._h, vp(reads_t.data_ptr()), reads_t.numel(), start.value, vp(indices.data_ptr()),
+                                               vp(pos.data_ptr()) if total.value else None, total.value, _stream_ptr()), "aix_positions_fill_dev")
+        return indices, pos
+
     def count13_t(self, plain_t, out_t=None):
         import torch
         self._chk_dev(plain_t)

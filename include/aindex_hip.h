@@ -200,6 +200,12 @@ int aix_window_codes_dev(const char* d_plain, uint64_t len, int k, int canon_mod
  * Any length: buffers of more than 2^30 windows are filled piece by piece, per-bucket fill counters carried over. */
 int aix_positions_fill(aix_index_t* h, const char* reads, uint64_t len, uint64_t* indices_out, uint64_t* positions_out,
                        uint64_t positions_cap, uint64_t* total_out);
+/* device-resident twin (reads, indices and positions in HBM; returns after the fill has completed on `stream`):
+ * aix_positions_total gives indices[n] = the size of d_positions_out; `start` is aix_positions_start() of the buffer
+ * (only the caller holds its head in host memory). */
+int aix_positions_total(aix_index_t* h, uint64_t* total_out);
+int aix_positions_fill_dev(aix_index_t* h, const char* d_reads, uint64_t len, uint64_t start, uint64_t* d_indices_out,
+                           uint64_t* d_positions_out, uint64_t positions_cap, void* stream);
 /* A2 over SHARDS of the reads file (multi-GPU). Shards are cut after '\n' (no window spans a cut).
  * aix_positions_bucket_counts: counts_out[h] (u64[n]) = windows of this shard that fall into bucket h under A2's rules;
  * aix_positions_fill_shard: the fill of this shard alone, with bucket h's slot numbering starting at filled_init[h]

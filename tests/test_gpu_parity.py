@@ -397,6 +397,20 @@ def test_positions_fill_equals_compute_aindex(ix23, gold, small23_prefix):
     assert np.array_equal(pos, z["index"])            # the reference's 1-thread run, slot for slot
 
 
+def test_positions_fill_device_twin(ix23, gold, small23_prefix):
+    """aix_positions_fill_dev (reads, indices, positions in HBM) == the host-buffer call == the reference's files; the
+    start adjustment is computed from the head the caller fetches."""
+    import torch
+    z = np.load(os.path.join(gold, "small23", "aindex.npz"))
+    reads = open(small23_prefix + ".reads", "rb").read()
+    for buf, want in ((reads, (z["indices"], z["index"])), (b"?AC\n" + reads[:9000], None), (b"ACGT\n" * 20000 + reads[:5000], None), (b"", None)):
+        if want is None:
+            want = O.OracleIndex23.from_prefix(small23_prefix).positions(buf)
+        t = torch.frombuffer(bytearray(buf) if buf else bytearray(1), dtype=torch.uint8)[: len(buf)].cuda()
+        ind, pos = ix23.positions_fill_t(t)
+        assert np.array_equal(ind.cpu().numpy().view(np.uint64), want[0]) and np.array_equal(pos.cpu().numpy().view(np.uint64), want[1])
+
+
 def test_positions_fill_vs_oracle_true_canonical(canon_case):
     ix, orc = canon_case["ix"], canon_case["orc"]
     asc = synth.genome_ascii(23, 300_000)
