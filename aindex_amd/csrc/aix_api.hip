@@ -587,7 +587,7 @@ extern "C" int aix_count13_dev(aix_index_t* h, const char* d_plain, uint64_t len
         HIPCHK(hipMemsetAsync(h->scratch13, 0, 8 * AIX_TOTAL_13MERS, s));
         HIPCHK(launch_count13_plain((const uint8_t*)d_plain, len, h->scratch13, s));
     } else {
-        // The partitioned path indexes windows with 32 bits: buffers are cut into pieces of at most `piece` window starts.
+        // The partitioned path indexes windows and chunks with 32 bits: buffers are cut into pieces of at most `piece` (2^31) window starts.
         // A window belongs to the piece that holds its first byte; a piece is handed its 12 following bytes as well, so the
         // cut needs no record boundary and every window is counted exactly once. Pieces after the first add to the table.
         uint64_t piece = 1ull << 31;

@@ -1,16 +1,19 @@
 // aix_count13.hip — 13-mer dense counting without global atomics (K13 row; count_kmers13.cpp:131-161).
 //
 // The 4^13 counter table (256 MiB as u32) is 1600x the LDS of a CU and 1.4e9 scattered memory-side atomics
-// run at ~23 G/s on MI355X (60 ms for 10 M reads). This path is HBM-streaming bound instead:
-//   P1 k_c13_sizes   : rolling 2-bit encode (32 window starts per lane), LDS histogram of the top 11 code
-//                      bits -> windows per (workgroup, partition); k_c13_colscan / k_c13_scan turn them into a
-//                      private, contiguous segment of every partition for every workgroup
-//   P2 k_c13_split   : same encode; a 32 768-window tile is counting-sorted by partition inside LDS and appended to
-//                      the workgroup's segment of each partition as coalesced runs of the low 15 code bits (u16)
-//   P3 k_c13_hist    : one workgroup per partition: 32 768 u32 counters in 128 KiB of LDS, ds_add per element,
-//                      counters stored (u64) to the code-ordered table — every bin written exactly once
-// then k_scatter13 permutes the table into the reference's mphf order.
+// run at ~23 G/s on MI355X (60 ms for 10 M reads). This path streams instead:
+//   k_c13_split_chunked : rolling 2-bit encode (32 window starts per lane, 4-byte SWAR); a 32 768-window tile is
+//                         counting-sorted inside LDS by the top 11 code bits (rank from one ds_add_rtn per window) and each
+//                         partition's run of low-15-bit payloads (u16) is appended to the workgroup's current 256-entry chunk
+//                         of that partition; chunk ids come from a per-workgroup region, handed out by the tile's block scan
+//   rocPRIM radix sort  : the chunk directory (partition of every chunk) -> per-partition chunk lists (a few M u16 keys)
+//   k_c13_hist_chunked  : one workgroup per partition: 32 768 u32 counters in 128 KiB of LDS, ds_add per element, counters
+//                         written through the code->mphf permutation — every bin of the output has exactly one writer
+// Nothing is sized before the split, so there is no separate counting pass over the input.
 #include <algorithm>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
 
 #include "aix_internal.hpp"
 
@@ -92,103 +95,78 @@ __device__ __forceinline__ Run13 encode_run13(const uint8_t* __restrict__ buf, u
     return r;
 }
 
-// P1: per-(workgroup, partition) window counts. Workgroup b owns tiles b, b+G, b+2G, ... in P1 and in P2 alike.
-__global__ void __launch_bounds__(C13_TB) k_c13_sizes(const uint8_t* __restrict__ buf, uint64_t len, uint64_t ntiles, uint32_t* __restrict__ cnt /* [G][P] */) {
-    __shared__ uint32_t hist[C13_P + C13_DUMMY];      // windows that do not count go to one of 64 scratch bins (no branch per window)
-    for (int i = threadIdx.x; i < C13_P + C13_DUMMY; i += C13_TB) hist[i] = 0;
-    __syncthreads();
-    for (uint64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const Run13 run = encode_run13(buf, len, t * C13_TILE + (uint64_t)threadIdx.x * C13_WPT);
-        const uint32_t dummy = C13_P + (threadIdx.x & (C13_DUMMY - 1));
-        for_each_window13<0>(run, [&](int, uint32_t code, uint32_t ok) { atomicAdd(&hist[ok ? code >> C13_BINBITS : dummy], 1u); });
-    }
-    __syncthreads();
-    uint32_t* row = cnt + (uint64_t)blockIdx.x * C13_P;
-    for (int i = threadIdx.x; i < C13_P; i += C13_TB) row[i] = hist[i];
-}
+// ---------------------------------------------------------------------------------------------
+// Chunked partitions: a workgroup's share of a partition is a list of 256-entry chunks, so nothing has to be sized
+// before the split (an earlier version ran a separate sizing pass — encode + 1.4e9 LDS atomics + a column scan, 1.2 ms per
+// 10 M reads — to give every workgroup an exact, contiguous segment of every partition). A directory (partition, fill)
+// per chunk, sorted by partition with one small radix sort, tells the histogram kernel which chunks belong to it.
+// ---------------------------------------------------------------------------------------------
+static constexpr int C13_CH = 256;                    // entries per chunk (512 B)
+static constexpr int C13_INFLIGHT = 8;                // chunk loads a wave of the histogram kernel keeps in flight
+static constexpr int C13_FILLBITS = 9;                // cursor = (chunk << 9) | fill, fill in [0, 256]; chunk = index inside the workgroup's region (< 2^23)
 
-// column scan: cnt[b][p] -> exclusive prefix over b (in place), part_count[p] = column total. One lane per partition.
-__global__ void __launch_bounds__(C13_TB) k_c13_colscan(uint32_t* __restrict__ cnt, uint32_t G, unsigned long long* __restrict__ part_count) {
-    const uint32_t p = blockIdx.x * C13_TB + threadIdx.x;
-    if (p >= (uint32_t)C13_P) return;
-    uint32_t run = 0;
-    for (uint32_t b = 0; b < G; ++b) {
-        const uint32_t c = cnt[(uint64_t)b * C13_P + p];
-        cnt[(uint64_t)b * C13_P + p] = run;
-        run += c;
-    }
-    part_count[p] = run;
-}
-
-// part_base[0..P] = exclusive scan of part_count. One workgroup.
-__global__ void __launch_bounds__(C13_TB) k_c13_scan(const unsigned long long* __restrict__ part_count, unsigned long long* __restrict__ part_base) {
-    __shared__ unsigned long long wsum[C13_TB / 64];
-    const int t = threadIdx.x;
-    const unsigned long long a = part_count[2 * t], b = part_count[2 * t + 1];
-    unsigned long long s = a + b;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const unsigned long long y = __shfl_up(s, d);
-        if ((t & 63) >= d) s += y;
-    }
-    if ((t & 63) == 63) wsum[t >> 6] = s;
-    __syncthreads();
-    unsigned long long off = 0;
-    for (int w = 0; w < (t >> 6); ++w) off += wsum[w];
-    const unsigned long long excl = off + s - (a + b);
-    part_base[2 * t] = excl;
-    part_base[2 * t + 1] = excl + a;
-    if (t == C13_TB - 1) part_base[C13_P] = off + s;
-}
-
-// P2: every workgroup appends to its own private segment of every partition (bases from P1), so no global atomics
-// are needed. A 32 768-window tile is counting-sorted by partition inside LDS (rank from one ds_add_rtn, packed
-// {partition, low 15 bits} entries), then written out as coalesced u16 runs. (Direct 2-byte scattered stores from the
-// lanes, without the LDS sort, were measured at 12.1 ms for this kernel against 4.4 ms with it.)
-__global__ void __launch_bounds__(C13_TB) k_c13_split(const uint8_t* __restrict__ buf, uint64_t len, uint64_t ntiles, const unsigned long long* __restrict__ part_base,
-                                                     const uint32_t* __restrict__ cnt /* [G][P] exclusive over workgroups */, uint16_t* __restrict__ parts) {
+// Chunk ids need no global allocator: a workgroup that sorts T tiles fills at most T * 128 + 2048 chunks (entries / 256
+// plus one partly filled chunk per partition), so workgroup b owns chunk ids [b * region, (b + 1) * region) and hands them
+// out with the same block scan that orders the tile (the per-partition chunk demand rides in the high half of the scan).
+__global__ void __launch_bounds__(C13_TB) k_c13_split_chunked(const uint8_t* __restrict__ buf, uint64_t len, uint64_t ntiles, uint32_t region,
+                                                             uint16_t* __restrict__ dir_part, uint16_t* __restrict__ dir_cnt, uint16_t* __restrict__ parts) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint32_t* hist = (uint32_t*)smem;                           // [P] tile-local count per partition
-    uint32_t* loc_off = hist + C13_P + C13_DUMMY;               // [P] exclusive scan of hist (hist has C13_DUMMY scratch bins behind it)
-    uint32_t* cursor = loc_off + C13_P;                         // [P] next free slot of this workgroup's segment (absolute)
-    uint32_t* wsum = cursor + C13_P;                            // [16]
+    uint32_t* hist = (uint32_t*)smem;                           // [P + DUMMY] tile-local count per partition; after the scan: first NEW chunk of the partition
+    uint32_t* loc_off = hist + C13_P + C13_DUMMY;               // [P] exclusive scan of hist
+    uint32_t* cursor = loc_off + C13_P;                         // [P] (current chunk << 9) | entries used in it (256 = none / full)
+    uint32_t* wsum = cursor + C13_P;                            // [16] per-wave totals: entries (low 16 bits, <= 32768), new chunks (high 16 bits, <= 2176)
     uint32_t* sorted = wsum + 16;                               // [TILE] (partition << 16) | low 15 bits, grouped by partition
     const int t = threadIdx.x;
-    {
-        const uint32_t* row = cnt + (uint64_t)blockIdx.x * C13_P;
-        cursor[2 * t] = (uint32_t)part_base[2 * t] + row[2 * t];            // nwin < 2^32
-        cursor[2 * t + 1] = (uint32_t)part_base[2 * t + 1] + row[2 * t + 1];
-        hist[2 * t] = 0;
-        hist[2 * t + 1] = 0;
-        if (t < C13_DUMMY) hist[C13_P + t] = 0;
-    }
+    constexpr uint32_t FILLMASK = (1u << C13_FILLBITS) - 1;
+    const uint32_t region_base = blockIdx.x * region;           // chunk ids below are relative to it
+    uint32_t next_chunk = 0;                                    // same value in every lane
+    cursor[2 * t] = C13_CH;
+    cursor[2 * t + 1] = C13_CH;
+    hist[2 * t] = 0;
+    hist[2 * t + 1] = 0;
+    if (t < C13_DUMMY) hist[C13_P + t] = 0;
     __syncthreads();
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         uint32_t rank[C13_WPT / 2];                              // two 16-bit ranks per register
         const Run13 run = encode_run13(buf, len, tile * C13_TILE + (uint64_t)t * C13_WPT);
-        const uint32_t dummy = C13_P + (t & (C13_DUMMY - 1));    // windows that do not count take a rank from a scratch bin: no branch
+        const uint32_t dummy = C13_P + (t & (C13_DUMMY - 1));
         for_each_window13<0>(run, [&](int j, uint32_t code, uint32_t ok) {
-            const uint32_t r = atomicAdd(&hist[ok ? code >> C13_BINBITS : dummy], 1u);   // < 2^16 (scratch bins: <= 512 per tile)
+            const uint32_t r = atomicAdd(&hist[ok ? code >> C13_BINBITS : dummy], 1u);
             if (j & 1) rank[j >> 1] |= r << 16; else rank[j >> 1] = r;
         });
         __syncthreads();
+        // this lane owns partitions 2t and 2t+1: entries a, b; fresh chunks k0, k1 = by how much they overflow the current chunk
         const uint32_t a = hist[2 * t], b = hist[2 * t + 1];
-        {   // exclusive scan of hist[2048]
-            uint32_t s = a + b;
+        const uint32_t c0 = cursor[2 * t], c1 = cursor[2 * t + 1];
+        const uint32_t tot0 = (c0 & FILLMASK) + a, tot1 = (c1 & FILLMASK) + b;
+        const uint32_t k0 = tot0 > (uint32_t)C13_CH ? (tot0 - 1) / C13_CH : 0u;    // = ceil((tot - CH) / CH)
+        const uint32_t k1 = tot1 > (uint32_t)C13_CH ? (tot1 - 1) / C13_CH : 0u;
+        uint32_t s = (a + b) | ((k0 + k1) << 16);               // one scan for both: a tile has <= 32768 entries and needs <= 2176 fresh chunks
+        const uint32_t mine = s;
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t y = __shfl_up(s, d);
-                if ((t & 63) >= d) s += y;
-            }
-            if ((t & 63) == 63) wsum[t >> 6] = s;
-            __syncthreads();
-            uint32_t off = 0;
-            for (int w = 0; w < (t >> 6); ++w) off += wsum[w];
-            const uint32_t excl = off + s - (a + b);
-            loc_off[2 * t] = excl;
-            loc_off[2 * t + 1] = excl + a;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(s, d);
+            if ((t & 63) >= d) s += y;
         }
-        __syncthreads();
+        if ((t & 63) == 63) wsum[t >> 6] = s;
+        __syncthreads();                                         // every lane has read its two counters: hist may be overwritten
+        uint32_t off = 0, all = 0;
+        for (int w = 0; w < C13_TB / 64; ++w) {
+            const uint32_t x = wsum[w];
+            if (w < (t >> 6)) off += x;
+            all += x;
+        }
+        const uint32_t excl = off + s - mine;
+        const uint32_t e0 = excl & 0xFFFFu, nb0 = next_chunk + (excl >> 16), nb1 = nb0 + k0;
+        loc_off[2 * t] = e0;
+        loc_off[2 * t + 1] = e0 + a;
+        hist[2 * t] = nb0;
+        hist[2 * t + 1] = nb1;
+        for (uint32_t i = 0; i < k0; ++i) if (nb0 + i < region) dir_part[region_base + nb0 + i] = (uint16_t)(2 * t);       // fill stays at the pre-set 256
+        for (uint32_t i = 0; i < k1; ++i) if (nb1 + i < region) dir_part[region_base + nb1 + i] = (uint16_t)(2 * t + 1);   // unless it ends up the last one
+        const uint32_t entries = all & 0xFFFFu;
+        next_chunk += all >> 16;
+        __syncthreads();                                         // loc_off and the chunk bases are complete
         for_each_window13<0>(run, [&](int j, uint32_t code, uint32_t ok) {
             if (ok) {
                 const uint32_t p = code >> C13_BINBITS;
@@ -197,63 +175,88 @@ __global__ void __launch_bounds__(C13_TB) k_c13_split(const uint8_t* __restrict_
             }
         });
         __syncthreads();
-        const uint32_t total = loc_off[C13_P - 1] + hist[C13_P - 1];
-        for (uint32_t i = t; i < total; i += C13_TB) {
+        for (uint32_t i = t; i < entries; i += C13_TB) {
             const uint32_t e = sorted[i];
             const uint32_t p = e >> 16;
-            parts[cursor[p] + (i - loc_off[p])] = (uint16_t)e;
+            const uint32_t c = cursor[p];
+            const uint32_t pos = (c & FILLMASK) + (i - loc_off[p]);
+            uint32_t chunk, o;
+            if (pos < (uint32_t)C13_CH) { chunk = c >> C13_FILLBITS; o = pos; }
+            else { chunk = hist[p] + (pos - C13_CH) / C13_CH; o = (pos - C13_CH) % C13_CH; }
+            if (chunk < region) parts[(uint64_t)(region_base + chunk) * C13_CH + o] = (uint16_t)e;
         }
         __syncthreads();
-        cursor[2 * t] += a;                                      // this lane owns partitions 2t, 2t+1
-        cursor[2 * t + 1] += b;
-        hist[2 * t] = 0;
-        hist[2 * t + 1] = 0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {                            // advance the two cursors this lane owns (recomputed: nothing but a, b stayed live)
+            const uint32_t p = 2 * t + q, c = cursor[p], tot = (c & FILLMASK) + (q ? b : a);
+            if (tot > (uint32_t)C13_CH) {
+                const uint32_t k = (tot - 1) / C13_CH;
+                cursor[p] = ((hist[p] + k - 1) << C13_FILLBITS) | (tot - k * C13_CH);
+            } else {
+                cursor[p] = (c & ~FILLMASK) | tot;
+            }
+            hist[p] = 0;
+        }
         if (t < C13_DUMMY) hist[C13_P + t] = 0;
         __syncthreads();
     }
+    // the chunk each (workgroup, partition) pair was still filling is the only one that is not full
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const uint32_t c = cursor[2 * t + q], fill = c & FILLMASK, chunk = c >> C13_FILLBITS;
+        if (fill < (uint32_t)C13_CH && chunk < region) dir_cnt[region_base + chunk] = (uint16_t)fill;
+    }
 }
 
-// One workgroup per partition. `perm` != nullptr: fused permutation — non-zero counters go straight to the
-// mphf-ordered output (pre-zeroed by the caller): out[perm[code]] = count. Otherwise every bin of the
-// code-ordered table is stored.
-__global__ void __launch_bounds__(C13_TB) k_c13_hist(const uint16_t* __restrict__ parts, const unsigned long long* __restrict__ part_base,
-                                                    unsigned long long* __restrict__ table, const uint32_t* __restrict__ perm, uint64_t* __restrict__ out_mphf,
-                                                    int accumulate) {
+// One workgroup per partition: its chunks are sdesc[lo, hi) of the directory sorted by partition (descriptor = chunk id in
+// the low half, entries in the high half). A wave fetches 64 descriptors with one coalesced load and then walks them with
+// v_readlane, eight 512-byte chunk loads in flight (64 KiB per CU), so no load depends on another one inside the loop.
+__global__ void __launch_bounds__(C13_TB) k_c13_hist_chunked(const uint16_t* __restrict__ parts, const uint16_t* __restrict__ spart /* sorted partition ids */,
+                                                            const uint64_t* __restrict__ sdesc, uint32_t cap, unsigned long long* __restrict__ table,
+                                                            const uint32_t* __restrict__ perm, uint64_t* __restrict__ out_mphf, int accumulate) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ uint32_t range[2];
     uint32_t* h = (uint32_t*)smem;                              // [BINS]
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t p = blockIdx.x; p < (uint32_t)C13_P; p += gridDim.x) {
         for (int i = threadIdx.x; i < C13_BINS; i += C13_TB) h[i] = 0;
+        if (threadIdx.x < 2) {                                  // lower_bound of p and of p + 1 in the sorted partition ids
+            const uint32_t key = p + threadIdx.x;
+            uint32_t lo = 0, hi = cap;
+            while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (spart[mid] < key) lo = mid + 1; else hi = mid; }
+            range[threadIdx.x] = lo;
+        }
         __syncthreads();
-        const unsigned long long lo = part_base[p], hi = part_base[p + 1];
-        // head up to a 16-byte boundary, then 8 codes per lane per load, then the tail
-        const unsigned long long lo8 = (lo + 7) & ~7ull, hi8 = hi & ~7ull;
-        if (lo8 < hi8) {
-            for (unsigned long long i = lo + threadIdx.x; i < lo8; i += C13_TB) atomicAdd(&h[parts[i]], 1u);
-            const uint4* v = (const uint4*)(parts + lo8);
-            const unsigned long long nv = (hi8 - lo8) >> 3;
-            auto add8 = [&](const uint4& x) {
-                atomicAdd(&h[x.x & 0xFFFFu], 1u); atomicAdd(&h[x.x >> 16], 1u);
-                atomicAdd(&h[x.y & 0xFFFFu], 1u); atomicAdd(&h[x.y >> 16], 1u);
-                atomicAdd(&h[x.z & 0xFFFFu], 1u); atomicAdd(&h[x.z >> 16], 1u);
-                atomicAdd(&h[x.w & 0xFFFFu], 1u); atomicAdd(&h[x.w >> 16], 1u);
-            };
-            // one workgroup per CU: four 16-byte loads per lane in flight (64 KiB per CU) to cover the HBM latency
-            unsigned long long i = threadIdx.x;
-            for (; i + 3 * C13_TB < nv; i += 4 * C13_TB) {
-                const uint4 x0 = v[i], x1 = v[i + C13_TB], x2 = v[i + 2 * C13_TB], x3 = v[i + 3 * C13_TB];
-                add8(x0); add8(x1); add8(x2); add8(x3);
+        const uint32_t lo = range[0], hi = range[1];
+        for (uint32_t c0 = lo + wave * 64; c0 < hi; c0 += (C13_TB / 64) * 64) {
+            const uint64_t desc = (c0 + lane < hi) ? sdesc[c0 + lane] : 0ull;
+            const uint32_t d_id = (uint32_t)desc, d_n = (uint32_t)(desc >> 32);
+            const uint32_t nch = min(64u, hi - c0);
+            for (uint32_t u0 = 0; u0 < nch; u0 += C13_INFLIGHT) {
+                uint2 x[C13_INFLIGHT];
+                uint32_t n[C13_INFLIGHT];
+#pragma unroll
+                for (int u = 0; u < C13_INFLIGHT; ++u) {
+                    const uint32_t j = min(u0 + u, 63u);
+                    const uint32_t id = __builtin_amdgcn_readlane(d_id, j);
+                    n[u] = (u0 + u < nch) ? (uint32_t)__builtin_amdgcn_readlane(d_n, j) : 0u;      // lanes past hi hold n = 0 anyway
+                    x[u] = ((const uint2*)(parts + (uint64_t)id * C13_CH))[lane];                  // id = 0 for padding: a valid chunk, ignored through n = 0
+                }
+#pragma unroll
+                for (int u = 0; u < C13_INFLIGHT; ++u) {
+                    const uint32_t base = lane * 4;
+                    if (base + 0 < n[u]) atomicAdd(&h[x[u].x & 0xFFFFu], 1u);
+                    if (base + 1 < n[u]) atomicAdd(&h[x[u].x >> 16], 1u);
+                    if (base + 2 < n[u]) atomicAdd(&h[x[u].y & 0xFFFFu], 1u);
+                    if (base + 3 < n[u]) atomicAdd(&h[x[u].y >> 16], 1u);
+                }
             }
-            for (; i < nv; i += C13_TB) add8(v[i]);
-            for (unsigned long long i = hi8 + threadIdx.x; i < hi; i += C13_TB) atomicAdd(&h[parts[i]], 1u);
-        } else {
-            for (unsigned long long i = lo + threadIdx.x; i < hi; i += C13_TB) atomicAdd(&h[parts[i]], 1u);
         }
         __syncthreads();
         const uint64_t base = (uint64_t)p * C13_BINS;
         if (perm) {
             for (int i = threadIdx.x; i < C13_BINS; i += C13_TB) {
                 const uint32_t c = h[i];
-                // every bin has exactly one writer per launch, launches of one call are ordered on the stream: plain += is exact
                 if (c) { const uint32_t slot = perm[base + i]; if (slot < 67108864u) out_mphf[slot] = accumulate ? out_mphf[slot] + c : (uint64_t)c; }
             }
         } else {
@@ -263,36 +266,72 @@ __global__ void __launch_bounds__(C13_TB) k_c13_hist(const uint16_t* __restrict_
     }
 }
 
+// directory sort values: chunk id | entries << 32, generated on the fly from the counting iterator
+struct ChunkDesc {
+    const uint16_t* dir_cnt;
+    __host__ __device__ uint64_t operator()(uint32_t i) const { return (uint64_t)i | ((uint64_t)dir_cnt[i] << 32); }
+};
+
 static constexpr unsigned C13_MAXGRID = 512;
 
-// workspace: part_count[P] u64 | part_base[P+1] u64 | cnt[G][P] u32 | parts u16[nwin]
+static inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
+// chunk ids one workgroup can need: 128 per tile it sorts + one partly filled chunk per partition
+static inline uint32_t chunk_region(uint64_t nwin) {
+    const uint64_t ntiles = (nwin + C13_TILE - 1) / C13_TILE;
+    const uint64_t grid = std::min<uint64_t>(ntiles ? ntiles : 1, C13_MAXGRID);
+    return (uint32_t)((ntiles + grid - 1) / grid * (C13_TILE / C13_CH) + C13_P);
+}
+static inline uint32_t chunk_capacity(uint64_t nwin) {
+    const uint64_t ntiles = (nwin + C13_TILE - 1) / C13_TILE;
+    return (uint32_t)(std::min<uint64_t>(ntiles ? ntiles : 1, C13_MAXGRID) * chunk_region(nwin));
+}
+static size_t dir_sort_temp_bytes(uint32_t cap) {
+    size_t bytes = 0;
+    auto vals = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), ChunkDesc{nullptr});
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint16_t*)nullptr, (uint16_t*)nullptr, vals, (uint64_t*)nullptr, (size_t)cap, 0u, 12u, (hipStream_t)0);
+    return bytes;
+}
+
+// workspace (chunked path): (256 B unused) | dir_part u16[cap] | dir_cnt u16[cap] | spart u16[cap] | sdesc u64[cap] | sort temp | parts u16[cap * 256]
+// `len` = bytes handed to one launch (<= 2^31 + 12)
 uint64_t count13_workspace_bytes(uint64_t len) {
     const uint64_t nwin = len >= 13 ? len - 12 : 0;
-    return 8ull * C13_P + 8ull * (C13_P + 1) + 4ull * C13_P * C13_MAXGRID + 2ull * nwin + 64;
+    const uint64_t cap = chunk_capacity(nwin);
+    return 256 + 3 * align_up(2 * cap, 256) + align_up(8 * cap, 256) + align_up(dir_sort_temp_bytes((uint32_t)cap), 256) + 2 * cap * C13_CH + 256;
 }
 
 hipError_t launch_count13_partitioned(const uint8_t* buf, uint64_t len, void* workspace, unsigned long long* table, const uint32_t* perm,
                                       uint64_t* out_mphf, int accumulate, hipStream_t s) {
     const uint64_t nwin = len >= 13 ? len - 12 : 0;
-    unsigned long long* part_count = (unsigned long long*)workspace;
-    unsigned long long* part_base = part_count + C13_P;
-    uint32_t* cnt = (uint32_t*)(part_base + C13_P + 1);
-    uint16_t* parts = (uint16_t*)(((uintptr_t)(cnt + (uint64_t)C13_P * C13_MAXGRID) + 15) & ~(uintptr_t)15);   // 16-byte aligned for uint4 loads
+    if (nwin > (1ull << 31)) return hipErrorInvalidValue;
+    const uint32_t cap = chunk_capacity(nwin);
+    uint8_t* w = (uint8_t*)workspace;
+    w += 256;
+    uint16_t* dir_part = (uint16_t*)w;                        w += align_up(2ull * cap, 256);
+    uint16_t* dir_cnt = (uint16_t*)w;                         w += align_up(2ull * cap, 256);
+    uint16_t* spart = (uint16_t*)w;                           w += align_up(2ull * cap, 256);
+    uint64_t* sdesc = (uint64_t*)w;                           w += align_up(8ull * cap, 256);
+    size_t tmp_bytes = dir_sort_temp_bytes(cap);
+    void* tmp = w;                                            w += align_up(tmp_bytes, 256);
+    uint16_t* parts = (uint16_t*)w;
     const uint64_t ntiles = (nwin + C13_TILE - 1) / C13_TILE;
     const unsigned grid = (unsigned)std::min<uint64_t>(ntiles ? ntiles : 1, C13_MAXGRID);
-    const size_t hist_lds = 4 * C13_BINS;                                   // 131 072 B
+    const size_t hist_lds = 4 * C13_BINS;                                       // 131 072 B
     const size_t split_lds = 4 * (3 * C13_P + C13_DUMMY + 16) + 4 * C13_TILE;   // 155 968 B
     {   // > 64 KiB of dynamic LDS needs the attribute; set per call (cheap, and correct for every device / thread)
-        hipError_t e = hipFuncSetAttribute((const void*)k_c13_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_c13_hist_chunked, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)k_c13_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)split_lds);
+        e = hipFuncSetAttribute((const void*)k_c13_split_chunked, hipFuncAttributeMaxDynamicSharedMemorySize, (int)split_lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_c13_sizes, dim3(grid), dim3(C13_TB), 0, s, buf, len, ntiles, cnt);
-    hipLaunchKernelGGL(k_c13_colscan, dim3(C13_P / C13_TB), dim3(C13_TB), 0, s, cnt, grid, part_count);
-    hipLaunchKernelGGL(k_c13_scan, dim3(1), dim3(C13_TB), 0, s, part_count, part_base);
-    hipLaunchKernelGGL(k_c13_split, dim3(grid), dim3(C13_TB), split_lds, s, buf, len, ntiles, part_base, cnt, parts);
-    hipLaunchKernelGGL(k_c13_hist, dim3(C13_P), dim3(C13_TB), hist_lds, s, parts, part_base, table, perm, out_mphf, accumulate);
+    hipError_t e = hipMemsetD16Async((hipDeviceptr_t)dir_part, (unsigned short)C13_P, cap, s);     // "no partition": sorts behind every real one
+    if (e == hipSuccess) e = hipMemsetD16Async((hipDeviceptr_t)dir_cnt, (unsigned short)C13_CH, cap, s);     // chunks are full unless the split says otherwise
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_c13_split_chunked, dim3(grid), dim3(C13_TB), split_lds, s, buf, len, ntiles, chunk_region(nwin), dir_part, dir_cnt, parts);
+    auto vals = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), ChunkDesc{dir_cnt});
+    e = rocprim::radix_sort_pairs(tmp, tmp_bytes, (const uint16_t*)dir_part, spart, vals, sdesc, (size_t)cap, 0u, 12u, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_c13_hist_chunked, dim3(C13_P), dim3(C13_TB), hist_lds, s, parts, spart, sdesc, cap, table, perm, out_mphf, accumulate);
     return hipGetLastError();
 }
 

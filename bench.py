@@ -454,7 +454,7 @@ def main():
                     "config": {"workload": "configs[1]: 13-mer dense 4^13 table count of 150 bp reads + all-reduce", "reads_per_step_per_gpu": a.reads},
                     **({"cpu_baseline": cb.get("reference", cb["port_mt"]), "cpu_baseline_extra": cb} if cb else {}),
                     "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                                 "traffic": None, "kernel": "k_count13 (+memset, scatter)", "kernel_ms": kern_ms}})
+                                 "traffic": None, "kernel": "k_c13_split_chunked + directory sort + k_c13_hist_chunked (+ memset of the table)", "kernel_ms": kern_ms}})
 
     elif a.workload == "count23":
         ix, g, keys, counts, pf = build_index23(a.genome, rank, world, dev, cache)

@@ -30,9 +30,8 @@ def mean_for(name, kern):
 summary = {}
 for tag, kern, passes in (("lookup23", "k_lookup23_ascii", ["l23_fetch", "l23_write", "l23_tcc", "l23_ea", "l23_sq"]),
                           ("gather_4GiB_16B", "k_gather", ["gather_fetch", "gather_ea"]),
-                          ("count13_split", "k_c13_split", ["c13_fetch", "c13_write", "c13_lds"]),
-                          ("count13_hist", "k_c13_hist", ["c13_fetch", "c13_write", "c13_lds"]),
-                          ("count13_sizes", "k_c13_sizes", ["c13_fetch", "c13_write", "c13_lds"])):
+                          ("count13_split", "k_c13_split_chunked", ["c13_fetch", "c13_write", "c13_lds"]),
+                          ("count13_hist", "k_c13_hist_chunked", ["c13_fetch", "c13_write", "c13_lds"])):
     d = {}
     for p in passes:
         d.update(mean_for(p, kern))
