@@ -91,18 +91,14 @@ __device__ __forceinline__ Q23 query23(const IndexDev& ix, uint64_t w0, uint64_t
     Q23 out;
     out.slot = 0; out.tf = 0; out.strand = 0; out.lines = 0;
     if (CANON && e.valid) {
-        // every stored code is canonical: only the canonical strand of the query can match
-        if (e.code <= r) {
-            const Probe p = probe23(ix, w0, w1, w2, e.code);
-            out.lines = p.lines;
-            if (p.found) { out.slot = p.slot; out.tf = p.tf; out.strand = 1; }
-        } else {
-            uint64_t r0, r1, r2;
-            ascii23_of_rc(e.code, r0, r1, r2);
-            const Probe p = probe23(ix, r0, r1, r2, r);
-            out.lines = p.lines;
-            if (p.found) { out.slot = p.slot; out.tf = p.tf; out.strand = 2; }
-        }
+        // every stored code is canonical: only the canonical strand of the query can match. ONE probe call site: with the
+        // strands chosen per lane first, a wave runs Jenkins + the MPHF walk once, not once per strand with half its lanes idle
+        const bool fwd = e.code <= r;
+        uint64_t x0 = w0, x1 = w1, x2 = w2;
+        if (!fwd) ascii23_of_rc(e.code, x0, x1, x2);
+        const Probe p = probe23(ix, x0, x1, x2, fwd ? e.code : r);
+        out.lines = p.lines;
+        if (p.found) { out.slot = p.slot; out.tf = p.tf; out.strand = fwd ? 1u : 2u; }
         return out;
     }
     const Probe f = probe23(ix, w0, w1, w2, e.code, e.valid);  // raw bytes hashed, sanitised code compared

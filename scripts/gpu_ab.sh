@@ -1,11 +1,13 @@
 #!/bin/bash
 set -e
 mkdir -p gpurun_out/ab
-cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/ab/prof_c13 -o c13 --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --workload count13 --steps 10 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
-cd $GRAFT_REPO_ROOT
-python - <<'PY'
-import csv
-for r in list(csv.DictReader(open('gpurun_out/ab/prof_c13/c13_kernel_stats.csv')))[:6]:
-    print(r['Name'][:70].replace('\n',' '), r['Calls'], '%.3f ms avg' % (float(r['AverageNs'])/1e6))
-PY
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -m gpu -x -q -k "tf or lookup or quer or golden or mirror or coverage" > gpurun_out/ab/pytest.log 2>&1 || { tail -30 gpurun_out/ab/pytest.log; exit 1; }
+tail -2 gpurun_out/ab/pytest.log
+for extra in "" "--query-mix" "--no-early-exit"; do
+timeout -k 10 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-secondary --no-gather-probe $extra > gpurun_out/ab/l23.json 2> gpurun_out/ab/l23.err
+python -c "
+import json; d=json.load(open('gpurun_out/ab/l23.json')); print('$extra', '%.4g' % d['value'], 'ms', d['ms_per_step'])"
+done
+timeout -k 10 300 python bench.py --workload coverage23 --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/ab/cov.json 2> gpurun_out/ab/cov.err
+python -c "
+import json; d=json.load(open('gpurun_out/ab/cov.json')); print('coverage', '%.4g' % d['value'], d['unit'], 'ms', d['ms_per_step'])"
