@@ -302,13 +302,26 @@ __global__ void __launch_bounds__(kBlock) k_coverage(const IndexDev ix, const ui
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     const uint32_t k = ix.k;
     for (uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x; p < total; p += stride) {
-        // sequence containing byte p: largest s with offs[s] <= p
-        uint64_t lo = 0, hi = M;                                // invariant offs[lo] <= p < offs[hi]
+        // sequence containing byte p: largest s with offs[s] <= p. The lanes of a wave hold consecutive p, so the binary search
+        // runs once per wave for its first position (wave-uniform: scalar loads), and a lane then walks forward from there —
+        // zero or one step unless the sequences are shorter than a wave is wide (then a bounded walk, then its own search).
+        const uint64_t p0 = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(p >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)p);
+        uint64_t lo = 0, hi = M;                                // invariant offs[lo] <= p0 < offs[hi] (or lo == 0)
         while (hi - lo > 1) {
             const uint64_t mid = (lo + hi) >> 1;
-            if (offs[mid] <= p) lo = mid; else hi = mid;
+            if (offs[mid] <= p0) lo = mid; else hi = mid;
         }
-        const uint64_t s = lo, begin = offs[s], end = offs[s + 1];
+        uint64_t s = lo;
+        for (int step = 0; step < 4 && s + 1 < M && offs[s + 1] <= p; ++step) ++s;
+        if (s + 1 < M && offs[s + 1] <= p) {
+            uint64_t l2 = s + 1, h2 = M;                        // offs[l2] <= p < offs[h2]
+            while (h2 - l2 > 1) {
+                const uint64_t mid = (l2 + h2) >> 1;
+                if (offs[mid] <= p) l2 = mid; else h2 = mid;
+            }
+            s = l2;
+        }
+        const uint64_t begin = offs[s], end = offs[s + 1];
         if (p < begin || p + k > end) continue;                 // p < begin: gaps between sequences are allowed
         uint32_t tf;
         if (k == 23) {

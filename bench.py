@@ -270,7 +270,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="lookup23", choices=["lookup23", "lookup13", "count13", "count23", "gather", "coverage23", "positions23", "normalize"])
+    ap.add_argument("--workload", default="lookup23", choices=["lookup23", "lookup13", "count13", "count23", "gather", "coverage23", "coverage13", "positions23", "normalize"])
     ap.add_argument("--seqs", type=int, default=100_000)
     ap.add_argument("--seq-len", type=int, default=10_000)
     ap.add_argument("--table-mib", type=int, default=4096)
@@ -494,6 +494,31 @@ def main():
                     "config": {"workload": f"configs[4]: per-position tf profile (k=23) of {L} bp sequences drawn from the indexed genome (50 % rc, 0.1 % N)",
                                "sequences_per_step_per_gpu": a.seqs, "positions_per_step": positions, "nonzero_fraction": float((outp != 0).float().mean().item())},
                     **({"cpu_baseline": cb} if cb else {}),
+                    "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                 "traffic": None, "kernel": "k_coverage", "kernel_ms": kern_ms, "positions_per_sec": positions / (kern_ms * 1e-3)}})
+
+    elif a.workload == "coverage13":
+        from aindex_amd.engine import Index
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from pf13 import pf13_path
+        ix = Index.open_13(pf13_path(), None, dev)
+        g = engine.synth_genome_t(13, 4_000_000, dev)
+        reads = engine.synth_reads_t(14, g, 1_000_000, 150, n_rate_ppm=1000)
+        ix.set_tf_13(ix.count13_t(reads).cpu().numpy().view(np.uint64))        # the 13-mer index of config 2 (counts of 1 M reads)
+        L = a.seq_len
+        seqs = engine.synth_reads_t(51, g, a.seqs, L, rc_half=False, n_rate_ppm=1000, first_read=rank * a.seqs)
+        offs = torch.arange(0, (a.seqs + 1) * (L + 1), L + 1, dtype=torch.int64, device=f"cuda:{dev}")
+        per = (L + 1) - 13 + 1
+        ooffs = torch.arange(0, (a.seqs + 1) * per, per, dtype=torch.int64, device=f"cuda:{dev}")
+        outp = torch.zeros(a.seqs * per, dtype=torch.int32, device=f"cuda:{dev}")
+        step = lambda: ix.coverage_t(seqs, offs, ooffs, a.seqs * per, 0, outp)
+        wall, kern_ms, _ = timed_steps(step, a.steps, a.warmup, dev)
+        positions = a.seqs * per
+        achieved = positions * (1.0 + 8.0 + 4.0) / (kern_ms * 1e-3) / 1e9      # one 8-byte read of the code-ordered table per position
+        out.update({"metric": "sequences_per_sec_coverage_13mer", "value": world * a.seqs * a.steps / wall, "unit": "sequences/s",
+                    "ms_per_step": wall / a.steps * 1e3, "dtype": "u64",
+                    "config": {"workload": f"configs[4]: per-position tf profile (k=13) of {L} bp sequences drawn from the counted genome (0.1 % N)",
+                               "sequences_per_step_per_gpu": a.seqs, "positions_per_step": positions, "nonzero_fraction": float((outp != 0).float().mean().item())},
                     "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                  "traffic": None, "kernel": "k_coverage", "kernel_ms": kern_ms, "positions_per_sec": positions / (kern_ms * 1e-3)}})
 
