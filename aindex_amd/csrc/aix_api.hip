@@ -1081,33 +1081,29 @@ extern "C" int aix_count_distinct(const char* buf, uint64_t len, int format, int
                                   uint64_t** counts_out, uint64_t* n_out) {
     if (!keys_out || !counts_out || !n_out || (len && !buf) || k < 1 || k > 31 || canon_mode < 0 || canon_mode > 2) return AIX_ERR_ARG;
     *keys_out = nullptr; *counts_out = nullptr; *n_out = 0;
-    if (len >> 32) return AIX_ERR_UNSUPPORTED;
     int st = check_device(device);
     if (st) return st;
     DevGuard g(device);
-    DevBuf d, dcodes;
+    DevBuf d;
     uint64_t plen = 0;
     st = stage_plain(nullptr, buf, len, format, 1, d, plen);
     if (st) return st;
     if (plen < (uint64_t)k) return AIX_OK;
-    const uint64_t nwin = plen - k + 1;
-    HIPCHK(dcodes.alloc(8 * nwin));
-    HIPCHK(launch_window_codes((const uint8_t*)d.p, plen, k, canon_mode, (uint64_t*)dcodes.p, 0));
-    uint64_t* dk = nullptr; uint32_t* dc = nullptr; uint64_t m = 0;
-    HIPCHK(distinct_from_codes((uint64_t*)dcodes.p, nwin, k, min_count ? min_count : 1, &dk, &dc, &m, 0));
+    uint64_t piece = 0;                                                        // 0: default (2^31 windows per sort)
+    if (const char* e = getenv("AIX_DISTINCT_PIECE")) piece = strtoull(e, nullptr, 10);   // test hook: exercise the merge at small sizes
+    uint64_t *dk = nullptr, *dc = nullptr, m = 0;
+    HIPCHK(distinct_from_plain((const uint8_t*)d.p, plen, k, canon_mode, min_count ? min_count : 1, piece, &dk, &dc, &m, 0));
     uint64_t* hk = (uint64_t*)malloc(8 * (m ? m : 1));
     uint64_t* hc = (uint64_t*)malloc(8 * (m ? m : 1));
-    std::vector<uint32_t> c32(m);
     hipError_t e = hipSuccess;
     if (!hk || !hc) { free(hk); free(hc); if (dk) (void)hipFree(dk); if (dc) (void)hipFree(dc); return AIX_ERR_NOMEM; }
     if (m) {
         e = hipMemcpy(hk, dk, 8 * m, hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(c32.data(), dc, 4 * m, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(hc, dc, 8 * m, hipMemcpyDeviceToHost);
     }
     if (dk) (void)hipFree(dk);
     if (dc) (void)hipFree(dc);
     if (e != hipSuccess) { free(hk); free(hc); set_last_error(std::string("count_distinct: ") + hipGetErrorString(e)); return AIX_ERR_HIP; }
-    for (uint64_t i = 0; i < m; ++i) hc[i] = c32[i];
     *keys_out = hk; *counts_out = hc; *n_out = m;
     return AIX_OK;
 }

@@ -222,7 +222,8 @@ int aix_positions_fill_shard(aix_index_t* h, const char* reads, uint64_t len, in
 /* K1 complete: replaces `kmer_counter <in.fa> <k> <out> [-t N] [-m min]` (src/count_kmers.cpp:235-382): the set of
  * (canonical k-mer code, count) with count >= min_count, sorted by code ascending (the reference sorts by count with
  * unspecified tie order; parity is on the set). *keys_out / *counts_out are malloc'd (aix_free). format as for the
- * counters (FASTA records follow count_kmers.cpp:250-295). 1 <= k <= 31, len < 2^32, counts < 2^32. */
+ * counters (FASTA records follow count_kmers.cpp:250-295). 1 <= k <= 31; any length (buffers of more
+ * than 2^31 windows are counted piece by piece and the distinct sets merged; counts are 64-bit). */
 int aix_count_distinct(const char* buf, uint64_t len, int format, int k, int canon_mode, uint64_t min_count, int device,
                        uint64_t** keys_out, uint64_t** counts_out, uint64_t* n_out);
 /* Host-side record normalisation to PLAIN form (readers of count_kmers13.cpp:211-272 /

@@ -163,6 +163,17 @@ def test_fuzz_normalise_and_distinct(seed):
             keys, counts = counting.count_distinct(buf, k, canon, 1 + seed % 2)
             okeys, ocnt = O.count_distinct(buf, k, canon, 1 + seed % 2)
             assert np.array_equal(keys, okeys) and np.array_equal(counts, ocnt), (seed, k, canon)
+    # counted piece by piece (what buffers beyond 2^31 windows go through): every cut position gives the same set
+    for piece in (1, 97, 4096):
+        os.environ["AIX_DISTINCT_PIECE"] = str(piece)
+        try:
+            small = buf[: 3000 if piece == 1 else len(buf)]
+            for k, canon, mc in ((13, 2, 1), (23, 1, 2), (31, 0, 1)):
+                keys, counts = counting.count_distinct(small, k, canon, mc)
+                okeys, ocnt = O.count_distinct(small, k, canon, mc)
+                assert np.array_equal(keys, okeys) and np.array_equal(counts, ocnt), (seed, piece, k, canon)
+        finally:
+            del os.environ["AIX_DISTINCT_PIECE"]
 
 
 @pytest.mark.parametrize("seed", range(10))
