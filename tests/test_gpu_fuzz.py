@@ -79,6 +79,22 @@ def test_fuzz_queries_counts_positions(seed, tmp_path):
         ind, pos = ix.positions_fill(buf)
         oind, opos = orc.positions(buf)
         assert np.array_equal(ind, oind) and np.array_equal(pos, opos)
+        # the multi-GPU shard protocols, replayed rank by rank: positions (tallies + carried slot numbering) and index scatter
+        from shard_helpers import positions_by_shards, scatter_by_shards
+        world = 2 + seed % 3
+        pfa = np.fromfile(prefix + ".pf", dtype=np.uint8)
+        ck, tfv = np.fromfile(prefix + ".kmers.bin", dtype=np.uint64), np.fromfile(prefix + ".tf.bin", dtype=np.uint32)
+        # (one tf of the case is 2^32-1, i.e. a 34 GB positions array per call: the shard replay runs on the same keys with tf <= 3)
+        with Index.create_23(pfa.tobytes(), ck, np.minimum(tfv, 3).astype(np.uint32)) as ix_small:
+            wind, wpos = ix_small.positions_fill(buf)
+            sind, spos, _ = positions_by_shards(ix_small, buf, world)
+            assert np.array_equal(sind, wind) and np.array_equal(spos, wpos), (seed, world)
+        n = ck.shape[0]
+        perm = rng.permutation(n)                                         # the .dat order is not the slot order
+        cuts = [0] + sorted(int(x) for x in rng.integers(0, n + 1, size=world - 1)) + [n]
+        sc, stf, socc, sts, clash = scatter_by_shards(pfa, synth.decode_kmers(ck, 23)[perm], tfv[perm], n, cuts)
+        assert all(x == 0 for x in sts) and not clash, (seed, sts)
+        assert np.array_equal(sc, ck) and np.array_equal(stf, tfv)
         seqs = [buf[:200], buf[200:460], b"", buf[-30:]]
         for cutoff in (0, 5):
             for s, got in zip(seqs, ix.coverage(seqs, cutoff)):

@@ -464,9 +464,7 @@ def test_positions_fill_shards_equal_whole(canon_case, world):
     tallies, exclusive sum over earlier shards, shard fills into full-size arrays, sum == the unsharded fill == oracle.
     The buffer starts with a stretch without any clean window (the start adjustment carries into later shards), holds
     '?' right after it, lower-case reads, PE separators and repeated reads that overflow their buckets."""
-    import ctypes as C
-    from aindex_amd import dist as adist
-    from aindex_amd._lib import lib, vp
+    from shard_helpers import positions_by_shards
     ix, orc = canon_case["ix"], canon_case["orc"]
     asc = synth.genome_ascii(23, 300_000)
     r = synth.reads_plain(45, asc, 600, 150, rc_fraction_half=True, n_rate_ppm=2000).reshape(-1, 151).copy()
@@ -479,25 +477,8 @@ def test_positions_fill_shards_equal_whole(canon_case, world):
         buf = lead + body
         want_ind, want_pos = orc.positions(buf)
         assert np.array_equal(ix.positions_fill(buf)[1], want_pos)
-        bounds = [adist.shard_line_bounds(buf, k, world) for k in range(world)]
-        assert bounds[0][0] == 0 and bounds[-1][1] == len(buf) and all(bounds[k][1] == bounds[k + 1][0] for k in range(world - 1))
-        first, tallies = [], []
-        all_exhausted = True
-        for lo, hi in bounds:
-            a = np.frombuffer(buf[lo:hi], dtype=np.uint8)
-            st = C.c_uint64()
-            assert lib().aix_positions_start(a.ctypes.data_as(vp) if a.shape[0] else None, a.shape[0], C.byref(st)) == 0
-            first.append(all_exhausted)
-            all_exhausted = all_exhausted and (hi - lo < 23 or st.value >= hi - lo - 22)
-            tallies.append(ix.positions_bucket_counts(buf[lo:hi], first[-1]))
-        total = int(want_ind[-1])
-        acc = np.zeros(total, dtype=np.uint64)
-        before = np.zeros(ix.n, dtype=np.uint64)
-        for (lo, hi), f, t in zip(bounds, first, tallies):
-            part = ix.positions_fill_shard(buf[lo:hi], total, f, lo, np.minimum(before, 2 ** 32 - 1).astype(np.uint32))
-            assert not np.any((acc != 0) & (part != 0))                   # every slot has one owner
-            acc += part
-            before += t
+        sind, acc, first = positions_by_shards(ix, buf, world)
+        assert np.array_equal(sind, want_ind)
         assert np.array_equal(ix.positions_indices(), want_ind) and np.array_equal(acc, want_pos), (world, len(lead))
         if lead.startswith(b"ACGTAC"):
             assert first[1] is True                                       # the adjustment did carry into the second shard
