@@ -222,6 +222,48 @@ def make_small23():
     print("small23 n =", len(rows), "queries =", len(q), "nonzero tf =", sum(1 for x in exp["tf"] if x))
 
 
+def make_small23_access():
+    """N2: positions / reads access of the reference's pybind module on the small23 pipeline (compute_reads ->
+    compute_aindex re-run into TMP from the committed fixtures; the .ridx is committed because the mirror needs it)."""
+    d = os.path.join(GOLD, "small23")
+    w = os.path.join(TMP, "small23_access")
+    shutil.rmtree(w, ignore_errors=True)
+    os.makedirs(w)
+    fa = os.path.join(d, "reads.fa")
+    pf = os.path.join(d, "small23.pf")
+    run([os.path.join(REF, "compute_reads"), fa, "-", "fasta", os.path.join(w, "small23")])
+    assert open(os.path.join(w, "small23.reads"), "rb").read() == open(os.path.join(d, "small23.reads"), "rb").read()
+    shutil.copy(os.path.join(w, "small23.ridx"), os.path.join(d, "small23.ridx"))
+    run([os.path.join(REF, "compute_aindex"), os.path.join(w, "small23.reads"), pf, os.path.join(w, "small23"), "1", "23",
+         os.path.join(d, "small23.tf.bin"), os.path.join(d, "small23.kmers.bin"), os.path.join(w, "none.txt")])
+    m = import_ref_module()
+    wr = m.AindexWrapper()
+    wr.load_from_prefix_23mer(os.path.join(d, "small23"))
+    wr.load_aindex_from_prefix_23mer(os.path.join(w, "small23"), 100, os.path.join(w, "small23.reads"))
+    rows = [ln.split("\t") for ln in open(os.path.join(d, "small23.dat")).read().split("\n") if ln]
+    stored = [r[0] for r in rows]
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    rc = lambda s: "".join(comp[c] for c in reversed(s))
+    # only k-mers get_pfid can find (hash.hpp:150-170 looks up the lexicographically smaller strand, so the STORED strand must
+    # be that one): on anything else get_positions aborts the reference process (SURVEY quirk 7)
+    ok = [s for s in stored if s <= rc(s)]
+    kmers = ok[:80] + [rc(s) for s in ok[80:140]] + ok[-40:]
+    pos = [list(wr.get_positions(s)) for s in kmers]
+    probes = sorted({p for ps in pos for p in ps})[:300] + [0, 1, 149, 150, 151, 152, 10 ** 9]
+    reads_size = wr.get_reads_size()
+    exp = {
+        "kmers": kmers, "positions": pos,
+        "probes": probes, "rid": [wr.get_rid(p) for p in probes], "start": [wr.get_start(p) for p in probes],
+        "n_reads": wr.n_reads, "reads_size": reads_size,
+        "read_by_rid": {str(r): wr.get_read_by_rid(r) for r in (0, 1, 2, 57, 398, 399, 400, 10 ** 6)},
+        "get_read": [[a, b, rcflag, wr.get_read(a, b, rcflag)] for a, b, rcflag in
+                     ((0, 150, False), (0, 150, True), (151, 200, False), (300, 310, True), (5, 5, False), (10, 5, False),
+                      (reads_size - 10, reads_size - 1, False), (reads_size - 1, reads_size, False), (reads_size, reads_size + 5, False))],
+    }
+    json.dump(exp, open(os.path.join(d, "access.json"), "w"), indent=0)
+    print("small23 access: kmers", len(kmers), "positions", sum(len(x) for x in pos), "probes", len(probes))
+
+
 def make_kmer_counter():
     d = os.path.join(GOLD, "kmer_counter")
     os.makedirs(d, exist_ok=True)
@@ -388,6 +430,8 @@ if __name__ == "__main__":
         make_codec()
     if not only or "small23" in only:
         make_small23()
+    if not only or "small23_access" in only:
+        make_small23_access()
     if not only or "kmer_counter" in only:
         make_kmer_counter()
     if not only or "compute_reads" in only:

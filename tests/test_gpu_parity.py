@@ -566,6 +566,59 @@ def test_python_mirrors(gold, small23_prefix, tmp_path):
     assert w.get_positions("ACGT") == [] and w.get_positions(qs[700]) == []
 
 
+def test_positions_and_reads_access_golden(gold, small23_prefix, tmp_path):
+    """N2: get_positions / get_rid / get_start / get_read_by_rid / get_read through the AIndex mirror == the answers of the
+    reference's compiled pybind module (tests/golden/small23/access.json, make_golden.py:make_small23_access), with the
+    positions files built by the GPU; then the pure-Python helpers layered on them."""
+    from aindex_amd.aindex import AIndex, hamming_distance
+    a = json.load(open(os.path.join(gold, "small23", "access.json")))
+    ai = AIndex.load_from_prefix(small23_prefix)
+    prefix = str(tmp_path / "acc")
+    ai._wrapper.build_aindex(small23_prefix + ".reads", prefix)
+    ai.load_aindex(prefix + ".index.bin", prefix + ".indices.bin", 100)
+    ai.load_reads(small23_prefix + ".reads")
+    assert ai.n_reads == a["n_reads"] and ai.reads_size == a["reads_size"] and ai.get_reads_size() == a["reads_size"]
+    assert [ai.get_positions(s) for s in a["kmers"]] == a["positions"]
+    assert [ai.pos(s) for s in a["kmers"][:5]] == a["positions"][:5]
+    assert [ai.get_rid(p) for p in a["probes"]] == a["rid"]
+    assert [ai.get_start(p) for p in a["probes"]] == a["start"]
+    for rid, read in a["read_by_rid"].items():
+        assert ai.get_read_by_rid(int(rid)) == read
+    for s0, e0, rcflag, want in a["get_read"]:
+        assert ai.get_read(s0, e0, rcflag) == want, (s0, e0, rcflag)
+    # helpers on top (aindex.py:271-343): every reported offset really holds the k-mer (or its reverse complement)
+    i0 = max(range(len(a["kmers"])), key=lambda i: len(a["positions"][i]))
+    k0 = a["kmers"][i0]
+    hits = ai.get_rid2poses(k0)
+    assert sum(len(v) for v in hits.values()) == len(a["positions"][i0]) > 0
+    rc0 = ai._wrapper.get_reverse_complement_23mer(k0)
+    for rid, offs in hits.items():
+        read = ai.get_read_by_rid(rid)
+        assert all(read[o:o + 23] in (k0, rc0) for o in offs)
+    got = ai.get_reads_by_kmer(k0, 3)
+    assert 0 < len(got) <= 3 and all(k0 in r or rc0 in r for r in got) and len(set(got)) == len(got)
+    reads = list(ai.iter_reads())
+    assert len(reads) == a["n_reads"] and reads[1] == (1, a["read_by_rid"]["1"])
+    assert sum(1 for _ in ai.iter_reads_se()) == a["n_reads"]                  # single-end reads: one sub-read each
+    assert ai.get_header(5) is None
+    hdr = str(tmp_path / "h.header")
+    open(hdr, "w").write("chr1.1 first\t0\t151\nchr2 second\t151\t151\n")
+    ai.load_reads_index(small23_prefix + ".ridx", hdr)
+    assert ai.get_header(150) == "chr1.1 first" and ai.get_header(151) == "chr2 second" and ai.get_header(10 ** 9) == ""
+    assert ai.chrm2start == {"chr1": 0, "chr2": 151} and ai.rid2start[1] == (151, 301)
+    assert hamming_distance("ACGTN", "ACCTA") == 1
+    # k-mers by frequency: the reference's enumeration (kid order, get_tf_value of the stored k-mer), stable descending sort
+    tf = np.fromfile(small23_prefix + ".tf.bin", dtype=np.uint32)
+    kmers = [ai.get_kmer_by_kid(i) for i in range(ai.n_kmers)]
+    want_tf = np.array(ai.get_tf_values(kmers), dtype=np.int64)
+    top = ai.get_top_kmers(25, min_tf=2, kmer_type="23mer")
+    order = [i for i in np.argsort(-want_tf, kind="stable") if want_tf[i] >= 2][:25]
+    assert top == [(kmers[i], int(want_tf[i])) for i in order] and top[0][1] == int(tf.max())
+    st = ai.get_kmer_frequency_stats()
+    assert st["kmer_type"] == "23mer" and st["total_kmers"] == ai.n_kmers and st["max_tf"] == int(tf.max()) and st["total_tf"] == int(want_tf.sum())
+    assert st["non_zero_kmers"] + st["zero_kmers"] == st["total_kmers"] and abs(st["avg_tf"] - want_tf[want_tf > 0].mean()) < 1e-9
+
+
 def test_tools_cli(gold, small23_prefix, tmp_path):
     from aindex_amd import tools
     out = str(tmp_path / "o")
