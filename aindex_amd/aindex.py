@@ -311,23 +311,10 @@ class AIndex:
         return hits
 
     def get_reads_by_kmer(self, kmer: str, max_reads: int = 100) -> List[str]:
-        """Reads that contain an indexed occurrence of the k-mer, each once, in order of first occurrence, at most
-        max_reads. (The reference's get_reads_se_by_kmer, python_wrapper.cpp:857-911, indexes the offsets array with
-        values of the positions array and the other way round — undefined behaviour, no parity target.)"""
+        """aindex.py:162-166 over get_reads_se_by_kmer (see the wrapper for the one documented deviation)."""
         if not self._wrapper.aindex_loaded:
             raise RuntimeError("Aindex not loaded")
-        out, seen = [], set()
-        for p in self.pos(kmer):
-            rid = self.get_rid(p)
-            if rid in seen:
-                continue
-            seen.add(rid)
-            read = self.get_read_by_rid(rid)
-            if read:
-                out.append(read)
-            if len(out) >= max_reads:
-                break
-        return out
+        return self._wrapper.get_reads_se_by_kmer(kmer, max_reads)
 
     def iter_reads(self):
         if self.reads_size == 0:                                  # aindex.py:271-278

@@ -415,6 +415,37 @@ class AindexWrapper:
         seg = np.asarray(self._positions[int(self._indices[h]):int(self._indices[h + 1])])
         return (seg[seg != 0] - np.uint64(1)).tolist()
 
+    def get_reads_se_by_kmer(self, kmer: str, max_reads: int = 100) -> List[str]:
+        """Reads that hold an indexed occurrence of the k-mer, each read once, at most max_reads. The reference's version
+        (:857-911) walks `positions[kmer_id] .. positions[kmer_id + 1]` over `indices[]` — its two arrays crossed — with the
+        unverified mphf value of the k-mer: undefined behaviour, so there is no parity target; this is what it intends."""
+        if not self.aindex_loaded:
+            return []
+        out, seen = [], set()
+        for p in self.get_positions(kmer):
+            i = self._interval(p)
+            if i is None or i in seen:
+                continue
+            seen.add(i)
+            read = self.get_read_by_rid(int(self._ridx_rid[i]))
+            if read:
+                out.append(read)
+            if len(out) >= max_reads:
+                break
+        return out
+
+    def debug_kmer_tf_values(self):
+        """:913-936 — for the stored k-mers at slots 1, 10, 100, ...: one line per read that holds an indexed occurrence."""
+        if self._ix23 is None:
+            return
+        tf = self._ix23.tf_array()
+        for h in (1, 10, 100, 1000, 10000, 100000):
+            if h >= self.n_kmers:
+                continue
+            kmer = self.get_kmer_by_kid(h)
+            for _ in self.get_reads_se_by_kmer(kmer, 100):
+                print(kmer, kmer, h, int(tf[h]))
+
     def close(self):
         for ix in (self._ix23, self._ix13):
             if ix is not None:
