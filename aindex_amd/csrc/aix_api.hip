@@ -63,6 +63,7 @@ struct aix_index {
     unsigned long long* scratch13 = nullptr;   // code-ordered count table, lazily allocated
     void* work13 = nullptr;                    // partition workspace of the atomic-free counter (grow-only)
     uint64_t work13_bytes = 0;
+    hipEvent_t work13_done = nullptr;          // recorded behind every counting call: the next one (any stream) waits for it before touching the workspace
     uint64_t device_bytes = 0;
     bool canonical_only = false;
     bool canonical_fastpath = true;
@@ -200,6 +201,7 @@ static void destroy(aix_index* h) {
     if (h->perm13) (void)hipFree(h->perm13);
     if (h->scratch13) (void)hipFree(h->scratch13);
     if (h->work13) (void)hipFree(h->work13);
+    if (h->work13_done) (void)hipEventDestroy(h->work13_done);
     delete h;
 }
 
@@ -577,6 +579,14 @@ extern "C" int aix_count13_dev(aix_index_t* h, const char* d_plain, uint64_t len
     DevGuard g(h->device);
     std::lock_guard<std::mutex> lk(h->count_mutex);
     hipStream_t s = (hipStream_t)stream;
+    // the scratch table / partition workspace belong to the handle: calls are ordered behind one another even when they come
+    // in on different streams (the mutex only orders the enqueueing)
+    if (h->work13_done) HIPCHK(hipStreamWaitEvent(s, h->work13_done, 0));
+    else HIPCHK(hipEventCreateWithFlags(&h->work13_done, hipEventDisableTiming));
+    struct RecordOnExit {
+        hipEvent_t ev; hipStream_t st;
+        ~RecordOnExit() { (void)hipEventRecord(ev, st); }
+    } record_on_exit{h->work13_done, s};
     const bool use_atomics = getenv("AIX_COUNT13_ATOMICS") != nullptr;             // A/B switch for measurements / tests
     if (use_atomics) {
         if (!h->scratch13) {

@@ -476,6 +476,10 @@ def main():
 
     elif a.workload == "coverage23":
         ix, g, keys, counts, pf = build_index23(a.genome, rank, world, dev, cache)
+        if a.no_early_exit:
+            ix.set_early_exit(False)
+        if a.no_fingerprint:
+            ix.set_fingerprint_filter(False)
         L = a.seq_len
         seqs = engine.synth_reads_t(51, g, a.seqs, L, rc_half=True, n_rate_ppm=1000, first_read=rank * a.seqs)   # records of L bases + '\n'
         offs = torch.arange(0, (a.seqs + 1) * (L + 1), L + 1, dtype=torch.int64, device=f"cuda:{dev}")

@@ -935,6 +935,29 @@ def test_count13_in_pieces(ix13, piece):
     assert want.sum() > 0 and np.array_equal(got, want)
 
 
+def test_count13_two_streams_share_the_workspace(ix13):
+    """Counting calls on one handle share its partition workspace: issued back to back on two streams they must still
+    produce the results of two separate runs (the second call waits on an event recorded behind the first)."""
+    import torch
+    from aindex_amd import engine
+    g = engine.synth_genome_t(13, 1_000_000)
+    ra = engine.synth_reads_t(17, g, 600_000, 150, n_rate_ppm=1000)
+    rb = engine.synth_reads_t(18, g, 500_000, 150, n_rate_ppm=5000)
+    want_a, want_b = ix13.count13_t(ra).clone(), ix13.count13_t(rb).clone()
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(3):
+        with torch.cuda.stream(s1):
+            got_a = ix13.count13_t(ra)
+        with torch.cuda.stream(s2):
+            got_b = ix13.count13_t(rb)
+        with torch.cuda.stream(s1):
+            got_a2 = ix13.count13_t(ra)
+        torch.cuda.synchronize()
+        assert bool(torch.equal(got_a, want_a)) and bool(torch.equal(got_b, want_b)) and bool(torch.equal(got_a2, want_a))
+    assert not bool(torch.equal(want_a, want_b))
+
+
 @pytest.mark.slow
 def test_count13_beyond_4gib(ix13):
     """30 M reads = 4.53 GB > 2^32 bytes: three pieces through the partitioned path == scattered atomics; the total is
