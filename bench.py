@@ -284,7 +284,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather-probe", action="store_true", help="skip the live random-read roofline measurement")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary counting measurement of the default workload")
-    ap.add_argument("--reads23", type=int, default=2_000_000)
+    ap.add_argument("--reads23", type=int, default=10_000_000, help="reads per rank and step of the secondary counting measurement (config 4 has 25 M per GPU at N = 8)")
     ap.add_argument("--no-fastpath", action="store_true", help="force the reference's two-probe order")
     ap.add_argument("--no-fingerprint", action="store_true", help="disable the 4-bit fingerprint filter")
     ap.add_argument("--no-early-exit", action="store_true", help="disable the early-exit MPHF walk (presence masks)")
