@@ -211,6 +211,44 @@ def cpu_baseline_count13(ix, reads_t, n_sample, tmpdir, pf13):
     return res
 
 
+def cpu_baseline_distinct23(reads_t, n_sample, gpu_keys, gpu_counts, tmpdir):
+    """kmer_counter on the host for a bounded sample of the same reads (FASTA, one record per read): the compiled reference
+    binary (its default thread count, wall clock of the whole run: it reads text and writes ./output.txt) when oracle/_ref
+    is present, plus our C port; the reference's (k-mer, count) set is compared with the GPU's REF_X86 result."""
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from aindex_amd import synth
+    os.makedirs(tmpdir, exist_ok=True)
+    host = reads_t[: n_sample * 151].cpu().numpy().reshape(-1, 151)[:, :150]
+    fasta = b"".join(b">r\n" + bytes(r) + b"\n" for r in host)
+    res = {}
+    t = time.perf_counter(); ok, oc = O.count_distinct(fasta, 23, 1, 1); dt = time.perf_counter() - t
+    assert np.array_equal(ok, gpu_keys) and np.array_equal(oc.astype(np.int64), gpu_counts.astype(np.int64)), "CPU port and GPU disagree on the sample"
+    res["port_1t"] = {"value": n_sample / dt, "unit": "reads/s", "cores": 1, "kind": "port", "sample": f"first {n_sample} reads of the batch"}
+    exe = os.path.join(ROOT, "oracle", "_ref", "kmer_counter")
+    if os.path.exists(exe):
+        inp = os.path.join(tmpdir, "sample.fa")
+        open(inp, "wb").write(fasta)
+        try:
+            t = time.perf_counter()
+            subprocess.run([exe, inp, "23", os.path.join(tmpdir, "unused.txt")], cwd=tmpdir, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900, check=True)
+            dt = time.perf_counter() - t
+            rows = [ln.split("\t") for ln in open(os.path.join(tmpdir, "output.txt")).read().split("\n") if ln]
+            want = dict(zip((bytes(x).decode() for x in synth.decode_kmers(gpu_keys, 23)), (int(c) for c in gpu_counts)))
+            assert len(rows) == len(want) and all(want.get(k) == int(c) for k, c in rows), "reference kmer_counter and GPU disagree on the sample"
+            res["reference"] = {"value": n_sample / dt, "unit": "reads/s", "cores": os.cpu_count() or 1, "kind": "reference",
+                                "sample": f"first {n_sample} reads of the batch through oracle/_ref/kmer_counter (wall clock incl. its text I/O)"}
+        except Exception as e:
+            log(f"cpu_baseline: reference kmer_counter not usable ({type(e).__name__}: {e})")
+        for f in ("sample.fa", "output.txt", "unused.txt"):
+            try:
+                os.remove(os.path.join(tmpdir, f))
+            except OSError:
+                pass
+    return res
+
+
 def cpu_baseline_coverage23(ix, pf, seqs_t, L, out_t, per, n_seq, tmpdir):
     """The reference's coverage path — AIndex.get_sequence_coverage's Python loop (aindex/core/aindex.py:314-322) over
     aindex_cpp.get_tf_value — on a few sequences of the batch, compared with the GPU profile."""
@@ -270,7 +308,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="lookup23", choices=["lookup23", "lookup13", "count13", "count23", "gather", "coverage23", "coverage13", "positions23", "normalize"])
+    ap.add_argument("--workload", default="lookup23", choices=["lookup23", "lookup13", "count13", "count23", "gather", "coverage23", "coverage13", "positions23", "normalize", "distinct23"])
     ap.add_argument("--seqs", type=int, default=100_000)
     ap.add_argument("--seq-len", type=int, default=10_000)
     ap.add_argument("--table-mib", type=int, default=4096)
@@ -538,6 +576,29 @@ def main():
                                "sequences_per_step_per_gpu": a.seqs, "positions_per_step": positions, "nonzero_fraction": float((outp != 0).float().mean().item())},
                     "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                  "traffic": None, "kernel": "k_coverage", "kernel_ms": kern_ms, "positions_per_sec": positions / (kern_ms * 1e-3)}})
+
+    elif a.workload == "distinct23":
+        from aindex_amd import counting
+        g = engine.synth_genome_t(23, a.genome, dev)
+        reads = engine.synth_reads_t(41, g, a.reads, 150, rc_half=True, n_rate_ppm=1000, first_read=rank * a.reads)
+        res = {}
+        step = lambda: res.__setitem__("o", counting.count_distinct_t(reads, 23, _lib.CANON_REF_X86, 1))
+        wall, kern_ms, _ = timed_steps(step, a.steps, a.warmup, dev)
+        keys_t, counts_t = res["o"]
+        windows = a.reads * (150 - 22)
+        achieved = (a.reads * 151 + windows * 8.0 * (1 + 2 * 6)) / (kern_ms * 1e-3) / 1e9      # codes written once, 6 radix passes read + write them
+        cb = None
+        if rank == 0 and world == 1 and not a.no_cpu_baseline:
+            ns = min(a.cpu_reads, a.reads)
+            sk, sc = counting.count_distinct_t(reads[: ns * 151], 23, _lib.CANON_REF_X86, 1)
+            cb = cpu_baseline_distinct23(reads, ns, sk.cpu().numpy().view(np.uint64), sc.cpu().numpy(), os.path.join(cache, "cpukc"))
+        out.update({"metric": "reads_per_sec_23mer_distinct_count", "value": world * a.reads * a.steps / wall, "unit": "reads/s",
+                    "ms_per_step": wall / a.steps * 1e3, "dtype": "u64",
+                    "config": {"workload": "K1 (kmer_counter): distinct canonical 23-mers of 150 bp reads with their counts, reads resident in HBM, per-rank sets (no exchange)",
+                               "reads_per_step_per_gpu": a.reads, "windows": windows, "distinct_kmers": int(keys_t.numel())},
+                    **({"cpu_baseline": cb.get("reference", cb["port_1t"]), "cpu_baseline_extra": cb} if cb else {}),
+                    "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                                 "kernel": "k_window_codes + torch.unique (radix sort + run-length)", "kernel_ms": kern_ms}})
 
     elif a.workload == "positions23":
         from aindex_amd._lib import lib, check, vp

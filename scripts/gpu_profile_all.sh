@@ -12,7 +12,7 @@ step "bench default"
 timeout -k 10 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err || { tail -20 $O/bench_default.err; exit 5; }
 echo "bench default wall $(( $(date +%s) - ts )) s" | tee -a $O/progress.txt; cat $O/bench_default.json
 step "secondary workloads"
-for w in "lookup23 --no-early-exit --no-cpu-baseline --no-secondary --no-gather-probe" "lookup23 --no-early-exit --no-fingerprint --no-cpu-baseline --no-secondary --no-gather-probe" "lookup23 --no-fastpath --no-cpu-baseline --no-secondary --no-gather-probe" "lookup23 --query-mix --cpu-sample 2000000 --no-secondary --no-gather-probe" "lookup23 --query-mix --no-early-exit --no-cpu-baseline --no-secondary --no-gather-probe" "lookup23 --gpu-builder --no-cpu-baseline --no-secondary --no-gather-probe" "lookup13" "count13" "count23 --reads 2000000" "coverage23" "coverage13" "positions23 --reads 5000000" "normalize --reads 5000000"; do
+for w in "lookup23 --no-early-exit --no-cpu-baseline --no-secondary --no-gather-probe" "lookup23 --no-early-exit --no-fingerprint --no-cpu-baseline --no-secondary --no-gather-probe" "lookup23 --no-fastpath --no-cpu-baseline --no-secondary --no-gather-probe" "lookup23 --query-mix --cpu-sample 2000000 --no-secondary --no-gather-probe" "lookup23 --query-mix --no-early-exit --no-cpu-baseline --no-secondary --no-gather-probe" "lookup23 --gpu-builder --no-cpu-baseline --no-secondary --no-gather-probe" "lookup13" "count13" "count23 --reads 2000000" "coverage23" "coverage13" "distinct23 --reads 5000000" "positions23 --reads 5000000" "normalize --reads 5000000"; do
   n=$(echo $w | sed 's/--no-cpu-baseline//; s/--no-secondary//; s/--no-gather-probe//; s/--cpu-sample 2000000//' | tr -d ' -'); timeout -k 10 600 python bench.py --workload $w --steps 5 --warmup 1 > $O/bench_$n.json 2> $O/bench_$n.err || { echo "$w failed"; tail -10 $O/bench_$n.err; exit 6; }
 done
 AIX_COUNT13_ATOMICS=1 timeout -k 10 600 python bench.py --workload count13 --steps 3 --warmup 1 > $O/bench_count13_atomics.json 2> /dev/null || exit 6
