@@ -98,11 +98,16 @@ SIGNATURES = {
     "aix_pf_build_ragged": (i32, [vp, vp, u64, C.POINTER(vp), C.POINTER(u64)]),
     "aix_pf_build_codes": (i32, [vp, u64, i32, C.POINTER(vp), C.POINTER(u64)]),
     "aix_index_scatter": (i32, [vp, u64, vp, vp, u64, i32, vp, vp]),
+    "aix_count_distinct_dev": (i32, [vp, u64, i32, i32, u64, i32, vp, C.POINTER(vp)]),
+    "aix_distinct_size": (i32, [vp, C.POINTER(u64)]),
+    "aix_distinct_copy_dev": (i32, [vp, vp, vp, vp]),
+    "aix_distinct_free": (None, [vp]),
     "aix_index_scatter_shard": (i32, [vp, u64, vp, vp, u64, u64, i32, vp, vp, vp]),
     "aix_index_build_23_codes_dev": (i32, [vp, u64, vp, vp, u64, i32, vp, C.POINTER(vp)]),
     "aix_pf_build_codes_dev": (i32, [vp, u64, i32, i32, vp, C.POINTER(vp), C.POINTER(u64)]),
     "aix_pf_build_all_13mers": (i32, [C.POINTER(vp), C.POINTER(u64)]),
     "aix_free": (None, [vp]),
+    "aix_scratch_trim": (None, []),
     "aix_selftest_mod": (u64, [u64, u64]),
     "aix_selftest_revcomp": (u64, [u64, i32]),
 }

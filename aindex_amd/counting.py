@@ -52,14 +52,23 @@ def window_codes_t(plain_t, k: int, canon_mode: int):
 
 
 def count_distinct_t(plain_t, k: int, canon_mode: int = _lib.CANON_TRUE_RC, min_count: int = 1):
-    """(keys int64 tensor sorted ascending, counts int64 tensor) for a PLAIN buffer already in HBM."""
+    """(keys int64 tensor sorted ascending, counts int64 tensor) for a PLAIN buffer already in HBM — aix_count_distinct_dev:
+    window-code kernel + rocPRIM radix sort / run-length inside the library; torch only owns the result tensors."""
     import torch
-    codes = window_codes_t(plain_t, k, canon_mode)
-    codes = codes[codes != -1]
-    keys, counts = torch.unique(codes, sorted=True, return_counts=True)
-    if min_count > 1:
-        keep = counts >= min_count
-        keys, counts = keys[keep], counts[keep]
+    dev = plain_t.device
+    res, n = vp(), C.c_uint64()
+    with torch.cuda.device(dev):
+        stream = vp(torch.cuda.current_stream().cuda_stream)
+        check(lib().aix_count_distinct_dev(vp(plain_t.data_ptr()), plain_t.numel(), k, canon_mode, min_count, dev.index, stream, C.byref(res)),
+              "aix_count_distinct_dev")
+        try:
+            check(lib().aix_distinct_size(res, C.byref(n)), "aix_distinct_size")
+            keys = torch.empty(n.value, dtype=torch.int64, device=dev)
+            counts = torch.empty(n.value, dtype=torch.int64, device=dev)
+            check(lib().aix_distinct_copy_dev(res, vp(keys.data_ptr()) if n.value else None, vp(counts.data_ptr()) if n.value else None, stream),
+                  "aix_distinct_copy_dev")
+        finally:
+            lib().aix_distinct_free(res)
     return keys, counts
 
 

@@ -41,10 +41,10 @@ struct DevGuard {   // switch to the handle's device for the duration of a call,
     ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
-struct DevBuf {
+struct DevBuf {                     // per-call temporary from the scratch pool; every user synchronises before it goes out of scope
     void* p = nullptr;
-    hipError_t alloc(uint64_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(uint64_t bytes) { return pool_alloc(&p, bytes ? bytes : 1); }
+    ~DevBuf() { if (p) { (void)hipDeviceSynchronize(); pool_free(p); } }   // whatever stream used it has drained
 };
 
 struct aix_index {
@@ -122,6 +122,8 @@ extern "C" int aix_device_count(int* count) {
     *count = c;
     return AIX_OK;
 }
+
+extern "C" void aix_scratch_trim(void) { pool_trim(); }
 
 extern "C" uint64_t aix_selftest_mod(uint64_t h, uint64_t d) { return fastmod(h, make_fastmod(d)); }
 extern "C" uint64_t aix_selftest_revcomp(uint64_t code, int k) { return revcomp(code, k); }
@@ -1087,6 +1089,50 @@ extern "C" int aix_positions_fill_shard(aix_index_t* h, const char* reads, uint6
 // ---------------------------------------------------------------------------------------------
 // K1: distinct canonical k-mers of a sequence file (kmer_counter replacement)
 // ---------------------------------------------------------------------------------------------
+// device-resident twin: the PLAIN buffer is already in HBM; the result stays in HBM inside an opaque object until the caller
+// has copied it into arrays of its own (two steps because the number of distinct k-mers is only known afterwards)
+struct aix_distinct { uint64_t* keys = nullptr; uint64_t* counts = nullptr; uint64_t n = 0; int device = 0; };
+
+extern "C" int aix_count_distinct_dev(const char* d_plain, uint64_t len, int k, int canon_mode, uint64_t min_count, int device, void* stream,
+                                      aix_distinct_t** out) {
+    if (!out || (len && !d_plain) || k < 1 || k > 31 || canon_mode < 0 || canon_mode > 2) return AIX_ERR_ARG;
+    *out = nullptr;
+    int st = check_device(device);
+    if (st) return st;
+    DevGuard g(device);
+    aix_distinct* r = new (std::nothrow) aix_distinct();
+    if (!r) return AIX_ERR_NOMEM;
+    r->device = device;
+    uint64_t piece = 0;
+    if (const char* e = getenv("AIX_DISTINCT_PIECE")) piece = strtoull(e, nullptr, 10);
+    hipError_t e = distinct_from_plain((const uint8_t*)d_plain, len, k, canon_mode, min_count ? min_count : 1, piece, &r->keys, &r->counts, &r->n, (hipStream_t)stream);
+    if (e != hipSuccess) { delete r; set_last_error(std::string("count_distinct: ") + hipGetErrorString(e)); return AIX_ERR_HIP; }
+    *out = r;
+    return AIX_OK;
+}
+extern "C" int aix_distinct_size(const aix_distinct_t* r, uint64_t* n_out) {
+    if (!r || !n_out) return AIX_ERR_ARG;
+    *n_out = r->n;
+    return AIX_OK;
+}
+extern "C" int aix_distinct_copy_dev(const aix_distinct_t* r, uint64_t* d_keys, uint64_t* d_counts, void* stream) {
+    if (!r || (r->n && (!d_keys || !d_counts))) return AIX_ERR_ARG;
+    DevGuard g(r->device);
+    if (r->n) {
+        HIPCHK(hipMemcpyAsync(d_keys, r->keys, 8 * r->n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        HIPCHK(hipMemcpyAsync(d_counts, r->counts, 8 * r->n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    }
+    return AIX_OK;
+}
+extern "C" void aix_distinct_free(aix_distinct_t* r) {
+    if (!r) return;
+    DevGuard g(r->device);
+    if (r->keys) pool_free(r->keys);
+    if (r->counts) pool_free(r->counts);
+    delete r;
+}
+
 extern "C" int aix_count_distinct(const char* buf, uint64_t len, int format, int k, int canon_mode, uint64_t min_count, int device, uint64_t** keys_out,
                                   uint64_t** counts_out, uint64_t* n_out) {
     if (!keys_out || !counts_out || !n_out || (len && !buf) || k < 1 || k > 31 || canon_mode < 0 || canon_mode > 2) return AIX_ERR_ARG;
@@ -1106,13 +1152,13 @@ extern "C" int aix_count_distinct(const char* buf, uint64_t len, int format, int
     uint64_t* hk = (uint64_t*)malloc(8 * (m ? m : 1));
     uint64_t* hc = (uint64_t*)malloc(8 * (m ? m : 1));
     hipError_t e = hipSuccess;
-    if (!hk || !hc) { free(hk); free(hc); if (dk) (void)hipFree(dk); if (dc) (void)hipFree(dc); return AIX_ERR_NOMEM; }
+    if (!hk || !hc) { free(hk); free(hc); if (dk) pool_free(dk); if (dc) pool_free(dc); return AIX_ERR_NOMEM; }
     if (m) {
         e = hipMemcpy(hk, dk, 8 * m, hipMemcpyDeviceToHost);
         if (e == hipSuccess) e = hipMemcpy(hc, dc, 8 * m, hipMemcpyDeviceToHost);
     }
-    if (dk) (void)hipFree(dk);
-    if (dc) (void)hipFree(dc);
+    if (dk) pool_free(dk);
+    if (dc) pool_free(dc);
     if (e != hipSuccess) { free(hk); free(hc); set_last_error(std::string("count_distinct: ") + hipGetErrorString(e)); return AIX_ERR_HIP; }
     *keys_out = hk; *counts_out = hc; *n_out = m;
     return AIX_OK;

@@ -29,6 +29,11 @@ struct LookupOut {
     uint8_t* strand;    // KIDSTRAND
 };
 
+// scratch pool (aix_pool.hip): cached device blocks for per-call temporaries; release only after the using stream is synchronised
+hipError_t pool_alloc(void** out, size_t bytes);
+void pool_free(void* p);
+void pool_trim();
+
 // launchers (aix_kernels.hip). All asynchronous on `stream`; return hipGetLastError().
 hipError_t launch_lookup23_ascii(const IndexDev& ix, const uint8_t* q, uint64_t N, int mode, LookupOut out, hipStream_t s);
 hipError_t launch_lookup23_codes(const IndexDev& ix, const uint64_t* codes, uint64_t N, uint32_t* out, hipStream_t s);

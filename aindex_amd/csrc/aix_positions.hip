@@ -113,17 +113,17 @@ __global__ void __launch_bounds__(kB) k_a2_tally(const uint32_t* __restrict__ ke
 hipError_t positions_indices(const IndexDev& ix, uint64_t* d_indices, hipStream_t s) {
     const uint64_t n = ix.n;
     uint64_t* tf64 = nullptr;
-    hipError_t e = hipMalloc((void**)&tf64, 8 * (n + 1));
+    hipError_t e = pool_alloc((void**)&tf64, 8 * (n + 1));
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_tf_u64, dim3(grid_of(n + 1)), dim3(kB), 0, s, ix.keys, n, tf64);
     size_t tmp_bytes = 0;
     e = rocprim::exclusive_scan(nullptr, tmp_bytes, tf64, d_indices, (uint64_t)0, (size_t)(n + 1), rocprim::plus<uint64_t>(), s);
     void* tmp = nullptr;
-    if (e == hipSuccess) e = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1);
+    if (e == hipSuccess) e = pool_alloc(&tmp, tmp_bytes ? tmp_bytes : 1);
     if (e == hipSuccess) e = rocprim::exclusive_scan(tmp, tmp_bytes, tf64, d_indices, (uint64_t)0, (size_t)(n + 1), rocprim::plus<uint64_t>(), s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (tmp) (void)hipFree(tmp);
-    (void)hipFree(tf64);
+    { const hipError_t es = hipStreamSynchronize(s); if (e == hipSuccess) e = es; }     // also on error paths: pool blocks are released idle
+    if (tmp) pool_free(tmp);
+    pool_free(tf64);
     return e;
 }
 
@@ -136,15 +136,15 @@ hipError_t positions_bucket_counts(const IndexDev& ix, const uint8_t* d_reads, u
     const uint64_t nwin_all = len - 22;
     const uint64_t pw = std::min<uint64_t>(1ull << 30, nwin_all);
     uint32_t* keys = nullptr;
-    hipError_t e = hipMalloc((void**)&keys, 4 * pw);
+    hipError_t e = pool_alloc((void**)&keys, 4 * pw);
     for (uint64_t w0 = 0; e == hipSuccess && w0 < nwin_all; w0 += pw) {
         const uint64_t nwin = std::min(pw, nwin_all - w0);
         hipLaunchKernelGGL(k_a2_probe, dim3(grid_of(nwin)), dim3(kB), 0, s, ix, d_reads + w0, nwin, start > w0 ? start - w0 : 0, keys);
         hipLaunchKernelGGL(k_a2_tally, dim3(grid_of(nwin)), dim3(kB), 0, s, keys, nwin, (uint32_t)ix.n, d_counts);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (keys) (void)hipFree(keys);
+    { const hipError_t es = hipStreamSynchronize(s); if (e == hipSuccess) e = es; }
+    if (keys) pool_free(keys);
     return e;
 }
 
@@ -158,18 +158,18 @@ hipError_t positions_fill(const IndexDev& ix, const uint8_t* d_reads, uint64_t l
     const uint64_t pw = std::min(piece, nwin_all);
     uint32_t *keys = nullptr, *skeys = nullptr, *svals = nullptr, *first = nullptr, *filled = nullptr;
     void* tmp = nullptr;
-    hipError_t e = hipMalloc((void**)&keys, 4 * pw);
-    if (e == hipSuccess) e = hipMalloc((void**)&skeys, 4 * pw);
-    if (e == hipSuccess) e = hipMalloc((void**)&svals, 4 * pw);
-    if (e == hipSuccess) e = hipMalloc((void**)&first, 4 * ix.n);
-    if (e == hipSuccess) e = hipMalloc((void**)&filled, 4 * ix.n);
+    hipError_t e = pool_alloc((void**)&keys, 4 * pw);
+    if (e == hipSuccess) e = pool_alloc((void**)&skeys, 4 * pw);
+    if (e == hipSuccess) e = pool_alloc((void**)&svals, 4 * pw);
+    if (e == hipSuccess) e = pool_alloc((void**)&first, 4 * ix.n);
+    if (e == hipSuccess) e = pool_alloc((void**)&filled, 4 * ix.n);
     if (e == hipSuccess) e = filled_init ? hipMemcpyAsync(filled, filled_init, 4 * ix.n, hipMemcpyDeviceToDevice, s) : hipMemsetAsync(filled, 0, 4 * ix.n, s);
     unsigned end_bit = 1;
     while (end_bit < 32 && (ix.n >> end_bit)) ++end_bit;                        // keys are in [0, n]
     size_t tmp_bytes = 0;
     rocprim::counting_iterator<uint32_t> iota(0);
     if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, skeys, iota, svals, (size_t)pw, 0u, end_bit, s);
-    if (e == hipSuccess) e = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1);
+    if (e == hipSuccess) e = pool_alloc(&tmp, tmp_bytes ? tmp_bytes : 1);
     for (uint64_t w0 = 0; e == hipSuccess && w0 < nwin_all; w0 += pw) {
         const uint64_t nwin = std::min(pw, nwin_all - w0);
         const uint64_t rel_start = start > w0 ? start - w0 : 0;               // windows before `start` get no bucket (hash.cpp:973-986)
@@ -184,13 +184,13 @@ hipError_t positions_fill(const IndexDev& ix, const uint8_t* d_reads, uint64_t l
             e = hipGetLastError();
         }
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (tmp) (void)hipFree(tmp);
-    if (keys) (void)hipFree(keys);
-    if (skeys) (void)hipFree(skeys);
-    if (svals) (void)hipFree(svals);
-    if (first) (void)hipFree(first);
-    if (filled) (void)hipFree(filled);
+    { const hipError_t es = hipStreamSynchronize(s); if (e == hipSuccess) e = es; }
+    if (tmp) pool_free(tmp);
+    if (keys) pool_free(keys);
+    if (skeys) pool_free(skeys);
+    if (svals) pool_free(svals);
+    if (first) pool_free(first);
+    if (filled) pool_free(filled);
     return e;
 }
 
@@ -222,18 +222,18 @@ hipError_t distinct_from_codes(uint64_t* d_codes /* clobbered */, uint64_t nwin,
     uint8_t* flags = nullptr;
     void* tmp = nullptr;
     size_t tb = 0;
-    hipError_t e = hipMalloc((void**)&sorted, 8 * nwin);
+    hipError_t e = pool_alloc((void**)&sorted, 8 * nwin);
     if (e == hipSuccess) e = rocprim::radix_sort_keys(nullptr, tb, d_codes, sorted, (size_t)nwin, 0u, (unsigned)(2 * k + 1), s);
-    if (e == hipSuccess) e = hipMalloc(&tmp, tb ? tb : 1);
+    if (e == hipSuccess) e = pool_alloc(&tmp, tb ? tb : 1);
     if (e == hipSuccess) e = rocprim::radix_sort_keys(tmp, tb, d_codes, sorted, (size_t)nwin, 0u, (unsigned)(2 * k + 1), s);
-    if (tmp) { (void)hipStreamSynchronize(s); (void)hipFree(tmp); tmp = nullptr; }
+    if (tmp) { (void)hipStreamSynchronize(s); pool_free(tmp); tmp = nullptr; }
     // run-length encode into the (now free) input buffer as unique keys, plus counts
     ukeys = d_codes;
-    if (e == hipSuccess) e = hipMalloc((void**)&ucnt, 4 * nwin);
-    if (e == hipSuccess) e = hipMalloc((void**)&d_runs, 8);
+    if (e == hipSuccess) e = pool_alloc((void**)&ucnt, 4 * nwin);
+    if (e == hipSuccess) e = pool_alloc((void**)&d_runs, 8);
     tb = 0;
     if (e == hipSuccess) e = rocprim::run_length_encode(nullptr, tb, sorted, (unsigned int)nwin, ukeys, ucnt, d_runs, s);   // size query
-    if (e == hipSuccess) e = hipMalloc(&tmp, tb ? tb : 1);
+    if (e == hipSuccess) e = pool_alloc(&tmp, tb ? tb : 1);
     uint64_t runs = 0;
     if (e == hipSuccess) {
         // rocPRIM takes the input size as unsigned int: encode in slices of < 2^31 and stitch equal boundary keys on the host
@@ -241,37 +241,38 @@ hipError_t distinct_from_codes(uint64_t* d_codes /* clobbered */, uint64_t nwin,
         e = rocprim::run_length_encode(tmp, tb, sorted, (unsigned int)nwin, ukeys, ucnt, d_runs, s);
     }
     if (e == hipSuccess) e = hipMemcpyAsync(&runs, d_runs, 8, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (tmp) { (void)hipFree(tmp); tmp = nullptr; }
-    if (sorted) { (void)hipFree(sorted); sorted = nullptr; }
+    { const hipError_t es = hipStreamSynchronize(s); if (e == hipSuccess) e = es; }
+    if (tmp) { pool_free(tmp); tmp = nullptr; }
+    if (sorted) { pool_free(sorted); sorted = nullptr; }
     // filter: drop the sentinel run and runs below min_count
     uint64_t* d_sel = nullptr;
     uint64_t kept = 0;
     if (e == hipSuccess && runs) {
-        e = hipMalloc((void**)&flags, runs);
-        if (e == hipSuccess) e = hipMalloc((void**)&fkeys, 8 * runs);
-        if (e == hipSuccess) e = hipMalloc((void**)&fcnt, 4 * runs);
-        if (e == hipSuccess) e = hipMalloc((void**)&d_sel, 8);
+        e = pool_alloc((void**)&flags, runs);
+        if (e == hipSuccess) e = pool_alloc((void**)&fkeys, 8 * runs);
+        if (e == hipSuccess) e = pool_alloc((void**)&fcnt, 4 * runs);
+        if (e == hipSuccess) e = pool_alloc((void**)&d_sel, 8);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(k_flag_min, dim3(grid_of(runs)), dim3(kB), 0, s, ucnt, runs, ukeys, sentinel,
                                (uint32_t)(min_count > 0xFFFFFFFFull ? 0xFFFFFFFFull : min_count), flags);
             tb = 0;
             e = rocprim::select(nullptr, tb, ukeys, flags, fkeys, d_sel, (size_t)runs, s);
         }
-        if (e == hipSuccess) e = hipMalloc(&tmp, tb ? tb : 1);
+        if (e == hipSuccess) e = pool_alloc(&tmp, tb ? tb : 1);
         if (e == hipSuccess) e = rocprim::select(tmp, tb, ukeys, flags, fkeys, d_sel, (size_t)runs, s);
         if (e == hipSuccess) e = rocprim::select(tmp, tb, ucnt, flags, fcnt, d_sel, (size_t)runs, s);
         if (e == hipSuccess) e = hipMemcpyAsync(&kept, d_sel, 8, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
     }
-    if (tmp) (void)hipFree(tmp);
-    if (flags) (void)hipFree(flags);
-    if (d_sel) (void)hipFree(d_sel);
-    if (d_runs) (void)hipFree(d_runs);
-    if (ucnt) (void)hipFree(ucnt);
+    (void)hipStreamSynchronize(s);
+    if (tmp) pool_free(tmp);
+    if (flags) pool_free(flags);
+    if (d_sel) pool_free(d_sel);
+    if (d_runs) pool_free(d_runs);
+    if (ucnt) pool_free(ucnt);
     if (e != hipSuccess) {
-        if (fkeys) (void)hipFree(fkeys);
-        if (fcnt) (void)hipFree(fcnt);
+        if (fkeys) pool_free(fkeys);
+        if (fcnt) pool_free(fcnt);
         return e;
     }
     *d_keys_out = fkeys; *d_counts_out = fcnt; *n_out = kept;
@@ -292,10 +293,14 @@ __global__ void __launch_bounds__(kB) k_flag_min64(const uint64_t* __restrict__ 
     for (uint64_t i = (uint64_t)blockIdx.x * kB + threadIdx.x; i < n; i += stride) flags[i] = counts[i] >= min_count ? 1 : 0;
 }
 
-struct DevArr {                       // tiny RAII holder, local to this function's error paths
+struct DevArr {                       // RAII holder of a pool block used on stream `st`: the stream is synchronised before the block goes back
     void* p = nullptr;
-    ~DevArr() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { if (p) { (void)hipFree(p); p = nullptr; } return hipMalloc(&p, bytes ? bytes : 1); }
+    hipStream_t st = nullptr;
+    DevArr() = default;
+    explicit DevArr(hipStream_t s) : st(s) {}
+    void drop() { if (p) { (void)hipStreamSynchronize(st); pool_free(p); p = nullptr; } }
+    ~DevArr() { drop(); }
+    hipError_t alloc(size_t bytes) { drop(); return pool_alloc(&p, bytes ? bytes : 1); }
     void* release() { void* q = p; p = nullptr; return q; }
 };
 
@@ -305,22 +310,22 @@ hipError_t distinct_from_plain(const uint8_t* d_plain, uint64_t plen, int k, int
     if (plen < (uint64_t)k) return hipSuccess;
     const uint64_t nwin_all = plen - k + 1;
     if (piece == 0 || piece > (1ull << 31)) piece = 1ull << 31;              // rocPRIM's run-length encode takes a 32-bit size
-    DevArr acc_k, acc_c;                                                      // merged distinct set so far
+    DevArr acc_k(s), acc_c(s);                                                // merged distinct set so far
     uint64_t acc_n = 0;
     hipError_t e = hipSuccess;
     for (uint64_t w0 = 0; e == hipSuccess && w0 < nwin_all; w0 += piece) {
         const uint64_t nwin = std::min(piece, nwin_all - w0);
-        DevArr codes;
+        DevArr codes(s);
         e = codes.alloc(8 * nwin);
         if (e == hipSuccess) e = launch_window_codes(d_plain + w0, nwin + k - 1, k, canon_mode, (uint64_t*)codes.p, s);
         uint64_t* pk = nullptr; uint32_t* pc = nullptr; uint64_t pm = 0;
         if (e == hipSuccess) e = distinct_from_codes((uint64_t*)codes.p, nwin, k, 1, &pk, &pc, &pm, s);
-        DevArr hold_k, hold_c; hold_k.p = pk; hold_c.p = pc;
+        DevArr hold_k(s), hold_c(s); hold_k.p = pk; hold_c.p = pc;
         if (e != hipSuccess || pm == 0) continue;
         // concatenate {acc, piece} as (key, u64 count), sort by key, sum equal keys
         const uint64_t tot = acc_n + pm;
         if (tot >> 32) { e = hipErrorInvalidValue; continue; }                // rocPRIM reduce_by_key takes a 32-bit size: < 2^32 distinct k-mers
-        DevArr cat_k, cat_c, srt_k, srt_c, out_k, out_c, d_n, tmp;
+        DevArr cat_k(s), cat_c(s), srt_k(s), srt_c(s), out_k(s), out_c(s), d_n(s), tmp(s);
         e = cat_k.alloc(8 * tot);
         if (e == hipSuccess) e = cat_c.alloc(8 * tot);
         if (e == hipSuccess && acc_n) e = hipMemcpyAsync(cat_k.p, acc_k.p, 8 * acc_n, hipMemcpyDeviceToDevice, s);
@@ -349,15 +354,15 @@ hipError_t distinct_from_plain(const uint8_t* d_plain, uint64_t plen, int k, int
         if (e == hipSuccess) e = hipMemcpyAsync(&merged, d_n.p, 8, hipMemcpyDeviceToHost, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         if (e == hipSuccess) {
-            if (acc_k.p) (void)hipFree(acc_k.p);
-            if (acc_c.p) (void)hipFree(acc_c.p);
+            if (acc_k.p) pool_free(acc_k.p);
+            if (acc_c.p) pool_free(acc_c.p);
             acc_k.p = out_k.release(); acc_c.p = out_c.release(); acc_n = merged;
         }
     }
     if (e != hipSuccess) return e;
     if (acc_n == 0) return hipSuccess;
     if (min_count > 1) {
-        DevArr flags, fk, fc, d_sel, tmp;
+        DevArr flags(s), fk(s), fc(s), d_sel(s), tmp(s);
         e = flags.alloc(acc_n);
         if (e == hipSuccess) e = fk.alloc(8 * acc_n);
         if (e == hipSuccess) e = fc.alloc(8 * acc_n);

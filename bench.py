@@ -598,7 +598,7 @@ def main():
                                "reads_per_step_per_gpu": a.reads, "windows": windows, "distinct_kmers": int(keys_t.numel())},
                     **({"cpu_baseline": cb.get("reference", cb["port_1t"]), "cpu_baseline_extra": cb} if cb else {}),
                     "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                                 "kernel": "k_window_codes + torch.unique (radix sort + run-length)", "kernel_ms": kern_ms}})
+                                 "kernel": "k_window_codes + rocPRIM radix sort / run-length (aix_count_distinct_dev)", "kernel_ms": kern_ms}})
 
     elif a.workload == "positions23":
         from aindex_amd._lib import lib, check, vp

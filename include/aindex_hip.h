@@ -62,7 +62,11 @@ typedef struct {
 
 const char* aix_version(void);
 const char* aix_strerror(int status);
-int aix_device_count(int* count);                     /* AIX_ERR_HIP if the runtime is unusable  */
+int aix_device_count(int* count);
+/* Calls that need multi-GB temporaries (K1, A1/A2, I1, host-buffer staging) take them from a per-device cache of device
+ * blocks (a hipMalloc of that size costs ~20 ms). AIX_SCRATCH_CACHE_GB (default 64) bounds the cache; this returns it
+ * to the driver. */
+void aix_scratch_trim(void);                     /* AIX_ERR_HIP if the runtime is unusable  */
 
 /* ------------------------------------------------------------------------------------------
  * Index lifecycle.
@@ -226,6 +230,14 @@ int aix_positions_fill_shard(aix_index_t* h, const char* reads, uint64_t len, in
  * than 2^31 windows are counted piece by piece and the distinct sets merged; counts are 64-bit). */
 int aix_count_distinct(const char* buf, uint64_t len, int format, int k, int canon_mode, uint64_t min_count, int device,
                        uint64_t** keys_out, uint64_t** counts_out, uint64_t* n_out);
+/* device-resident twin: d_plain is a PLAIN buffer in HBM; the (key, count) arrays stay in HBM inside *out until the caller
+ * has sized its own arrays (aix_distinct_size) and copied them (aix_distinct_copy_dev: u64 keys ascending, u64 counts). */
+typedef struct aix_distinct aix_distinct_t;
+int aix_count_distinct_dev(const char* d_plain, uint64_t len, int k, int canon_mode, uint64_t min_count, int device, void* stream,
+                           aix_distinct_t** out);
+int aix_distinct_size(const aix_distinct_t* r, uint64_t* n_out);
+int aix_distinct_copy_dev(const aix_distinct_t* r, uint64_t* d_keys, uint64_t* d_counts, void* stream);
+void aix_distinct_free(aix_distinct_t* r);
 /* Host-side record normalisation to PLAIN form (readers of count_kmers13.cpp:211-272 /
  * count_kmers.cpp:250-295): out must hold len+1 bytes; *out_len receives the normalised length.
  * fasta_mode: 0 = count_kmers13 rules, 1 = kmer_counter rules ('>' anywhere starts a record). */

@@ -1,10 +1,11 @@
 #!/bin/bash
 set -e
 mkdir -p gpurun_out/ab
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -m gpu -x -q -k "count23 or corrupt or (fuzz_queries and (1 or 2))" > gpurun_out/ab/pytest.log 2>&1 || { tail -30 gpurun_out/ab/pytest.log; exit 1; }
+timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/ab/pytest.log 2>&1 || { tail -30 gpurun_out/ab/pytest.log; exit 1; }
 tail -2 gpurun_out/ab/pytest.log
-for extra in "" "--no-node-table"; do
-timeout -k 10 300 python bench.py --workload count23 --steps 5 --warmup 2 $extra > gpurun_out/ab/c23.json 2> gpurun_out/ab/c23.err
+timeout -k 10 300 python bench.py --workload distinct23 --reads 5000000 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/ab/d23.json 2> gpurun_out/ab/d23.err
 python -c "
-import json; d=json.load(open('gpurun_out/ab/c23.json')); print('count23 $extra', '%.4g' % d['value'], d['unit'], 'ms', d['ms_per_step'], d['roofline']['random_read']['frac'])"
-done
+import json; d=json.load(open('gpurun_out/ab/d23.json')); print('distinct23', d['value'], d['ms_per_step'], d['config']['distinct_kmers'])"
+timeout -k 10 300 python bench.py --workload positions23 --reads 5000000 --steps 3 --warmup 1 > gpurun_out/ab/p23.json 2> gpurun_out/ab/p23.err
+python -c "
+import json; d=json.load(open('gpurun_out/ab/p23.json')); print('positions23', d['value'], d['ms_per_step'], d['config']['host_buffer_call_ms'])"
