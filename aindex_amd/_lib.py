@@ -99,6 +99,7 @@ SIGNATURES = {
     "aix_pf_build_codes": (i32, [vp, u64, i32, C.POINTER(vp), C.POINTER(u64)]),
     "aix_index_scatter": (i32, [vp, u64, vp, vp, u64, i32, vp, vp]),
     "aix_count_distinct_dev": (i32, [vp, u64, i32, i32, u64, i32, vp, C.POINTER(vp)]),
+    "aix_merge_counts_dev": (i32, [vp, vp, u64, u64, i32, vp, C.POINTER(vp)]),
     "aix_distinct_size": (i32, [vp, C.POINTER(u64)]),
     "aix_distinct_copy_dev": (i32, [vp, vp, vp, vp]),
     "aix_distinct_free": (None, [vp]),

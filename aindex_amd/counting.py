@@ -72,6 +72,28 @@ def count_distinct_t(plain_t, k: int, canon_mode: int = _lib.CANON_TRUE_RC, min_
     return keys, counts
 
 
+def merge_counts_t(keys_t, counts_t, min_count: int = 1):
+    """Device tensors of (key, count) pairs with repeated keys -> (keys ascending, summed counts >= min_count), all int64
+    (u64 bit patterns); aix_merge_counts_dev: rocPRIM sort + reduce-by-key inside the library."""
+    import torch
+    dev = keys_t.device
+    keys_t, counts_t = keys_t.contiguous(), counts_t.contiguous()
+    res, n = vp(), C.c_uint64()
+    with torch.cuda.device(dev):
+        stream = vp(torch.cuda.current_stream().cuda_stream)
+        check(lib().aix_merge_counts_dev(vp(keys_t.data_ptr()) if keys_t.numel() else None, vp(counts_t.data_ptr()) if keys_t.numel() else None,
+                                         keys_t.numel(), min_count, dev.index, stream, C.byref(res)), "aix_merge_counts_dev")
+        try:
+            check(lib().aix_distinct_size(res, C.byref(n)), "aix_distinct_size")
+            keys = torch.empty(n.value, dtype=torch.int64, device=dev)
+            counts = torch.empty(n.value, dtype=torch.int64, device=dev)
+            check(lib().aix_distinct_copy_dev(res, vp(keys.data_ptr()) if n.value else None, vp(counts.data_ptr()) if n.value else None, stream),
+                  "aix_distinct_copy_dev")
+        finally:
+            lib().aix_distinct_free(res)
+    return keys, counts
+
+
 def count_distinct(buf: bytes, k: int, canon_mode: int = _lib.CANON_TRUE_RC, min_count: int = 1, fmt: int = _lib.FMT_FASTA,
                    device: int = 0):
     """kmer_counter replacement for a host buffer, entirely behind the C ABI (aix_count_distinct: HIP window kernel +

@@ -1110,6 +1110,22 @@ extern "C" int aix_count_distinct_dev(const char* d_plain, uint64_t len, int k, 
     *out = r;
     return AIX_OK;
 }
+// K1 across GPUs: after the exchange a rank holds (key, count) pairs from every rank; equal keys are summed here
+extern "C" int aix_merge_counts_dev(const uint64_t* d_keys, const uint64_t* d_counts, uint64_t n, uint64_t min_count, int device, void* stream,
+                                    aix_distinct_t** out) {
+    if (!out || (n && (!d_keys || !d_counts))) return AIX_ERR_ARG;
+    *out = nullptr;
+    int st = check_device(device);
+    if (st) return st;
+    DevGuard g(device);
+    aix_distinct* r = new (std::nothrow) aix_distinct();
+    if (!r) return AIX_ERR_NOMEM;
+    r->device = device;
+    hipError_t e = merge_counts(d_keys, d_counts, n, min_count ? min_count : 1, &r->keys, &r->counts, &r->n, (hipStream_t)stream);
+    if (e != hipSuccess) { delete r; set_last_error(std::string("merge_counts: ") + hipGetErrorString(e)); return e == hipErrorInvalidValue ? AIX_ERR_UNSUPPORTED : AIX_ERR_HIP; }
+    *out = r;
+    return AIX_OK;
+}
 extern "C" int aix_distinct_size(const aix_distinct_t* r, uint64_t* n_out) {
     if (!r || !n_out) return AIX_ERR_ARG;
     *n_out = r->n;

@@ -76,6 +76,8 @@ hipError_t distinct_from_codes(uint64_t* d_codes, uint64_t nwin, int k, uint64_t
                                hipStream_t s);
 hipError_t distinct_from_plain(const uint8_t* d_plain, uint64_t plen, int k, int canon_mode, uint64_t min_count, uint64_t piece, uint64_t** d_keys_out,
                                uint64_t** d_counts_out, uint64_t* n_out, hipStream_t s);
+hipError_t merge_counts(const uint64_t* d_keys, const uint64_t* d_counts, uint64_t n, uint64_t min_count, uint64_t** d_keys_out, uint64_t** d_counts_out,
+                        uint64_t* n_out, hipStream_t s);
 
 // record normalisation on the device (aix_normalize.hip); d_out holds len + 1 bytes
 hipError_t normalise_device(const uint8_t* d_raw, uint64_t len, int format, int fasta_mode, uint8_t* d_out, uint64_t* out_len, hipStream_t s);

@@ -384,4 +384,50 @@ hipError_t distinct_from_plain(const uint8_t* d_plain, uint64_t plen, int k, int
     return hipSuccess;
 }
 
+// (key, count) pairs with repeated keys (the shares of several ranks after the K1 exchange) -> keys ascending, counts summed,
+// counts >= min_count. Inputs are not modified.
+hipError_t merge_counts(const uint64_t* d_keys, const uint64_t* d_counts, uint64_t n, uint64_t min_count, uint64_t** d_keys_out, uint64_t** d_counts_out,
+                        uint64_t* n_out, hipStream_t s) {
+    *d_keys_out = nullptr; *d_counts_out = nullptr; *n_out = 0;
+    if (n == 0) return hipSuccess;
+    if (n >> 32) return hipErrorInvalidValue;
+    DevArr srt_k(s), srt_c(s), out_k(s), out_c(s), d_n(s), tmp(s), flags(s), fk(s), fc(s);
+    hipError_t e = srt_k.alloc(8 * n);
+    if (e == hipSuccess) e = srt_c.alloc(8 * n);
+    size_t tb = 0;
+    if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, tb, d_keys, (uint64_t*)srt_k.p, d_counts, (uint64_t*)srt_c.p, (size_t)n, 0u, 64u, s);
+    if (e == hipSuccess) e = tmp.alloc(tb);
+    if (e == hipSuccess) e = rocprim::radix_sort_pairs(tmp.p, tb, d_keys, (uint64_t*)srt_k.p, d_counts, (uint64_t*)srt_c.p, (size_t)n, 0u, 64u, s);
+    if (e == hipSuccess) e = out_k.alloc(8 * n);
+    if (e == hipSuccess) e = out_c.alloc(8 * n);
+    if (e == hipSuccess) e = d_n.alloc(8);
+    tb = 0;
+    if (e == hipSuccess) e = rocprim::reduce_by_key(nullptr, tb, (uint64_t*)srt_k.p, (uint64_t*)srt_c.p, (unsigned int)n, (uint64_t*)out_k.p, (uint64_t*)out_c.p, (uint64_t*)d_n.p, rocprim::plus<uint64_t>(), rocprim::equal_to<uint64_t>(), s);
+    if (e == hipSuccess) e = tmp.alloc(tb);
+    if (e == hipSuccess) e = rocprim::reduce_by_key(tmp.p, tb, (uint64_t*)srt_k.p, (uint64_t*)srt_c.p, (unsigned int)n, (uint64_t*)out_k.p, (uint64_t*)out_c.p, (uint64_t*)d_n.p, rocprim::plus<uint64_t>(), rocprim::equal_to<uint64_t>(), s);
+    uint64_t merged = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&merged, d_n.p, 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return e;
+    if (min_count > 1 && merged) {
+        e = flags.alloc(merged);
+        if (e == hipSuccess) e = fk.alloc(8 * merged);
+        if (e == hipSuccess) e = fc.alloc(8 * merged);
+        if (e == hipSuccess) { hipLaunchKernelGGL(k_flag_min64, dim3(grid_of(merged)), dim3(kB), 0, s, (const uint64_t*)out_c.p, merged, min_count, (uint8_t*)flags.p); e = hipGetLastError(); }
+        tb = 0;
+        if (e == hipSuccess) e = rocprim::select(nullptr, tb, (uint64_t*)out_k.p, (uint8_t*)flags.p, (uint64_t*)fk.p, (uint64_t*)d_n.p, (size_t)merged, s);
+        if (e == hipSuccess) e = tmp.alloc(tb);
+        if (e == hipSuccess) e = rocprim::select(tmp.p, tb, (uint64_t*)out_k.p, (uint8_t*)flags.p, (uint64_t*)fk.p, (uint64_t*)d_n.p, (size_t)merged, s);
+        if (e == hipSuccess) e = rocprim::select(tmp.p, tb, (uint64_t*)out_c.p, (uint8_t*)flags.p, (uint64_t*)fc.p, (uint64_t*)d_n.p, (size_t)merged, s);
+        uint64_t kept = 0;
+        if (e == hipSuccess) e = hipMemcpyAsync(&kept, d_n.p, 8, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return e;
+        *d_keys_out = (uint64_t*)fk.release(); *d_counts_out = (uint64_t*)fc.release(); *n_out = kept;
+        return hipSuccess;
+    }
+    *d_keys_out = (uint64_t*)out_k.release(); *d_counts_out = (uint64_t*)out_c.release(); *n_out = merged;
+    return hipSuccess;
+}
+
 }  // namespace aix

@@ -165,7 +165,10 @@ def exchange_merge_counts(keys, counts, min_count: int = 1):
         dist.all_to_all_single(rc, counts.to(xdev), output_split_sizes=outs, input_split_sizes=ins)
         keys, counts = rk.to(dev), rc.to(dev)
     # local merge: equal keys from different ranks are summed (keys compare as u64: every valid code is < 2^62)
-    ukeys, inv = torch.unique(keys, sorted=True, return_inverse=True)
+    if keys.is_cuda:                                  # product path: sort + reduce-by-key inside the library
+        from .counting import merge_counts_t
+        return merge_counts_t(keys, counts, min_count)
+    ukeys, inv = torch.unique(keys, sorted=True, return_inverse=True)      # CPU tensors: the gloo tests' plumbing
     sums = torch.zeros(ukeys.numel(), dtype=torch.int64, device=keys.device)
     sums.index_add_(0, inv, counts)
     if min_count > 1:

@@ -235,6 +235,10 @@ int aix_count_distinct(const char* buf, uint64_t len, int format, int k, int can
 typedef struct aix_distinct aix_distinct_t;
 int aix_count_distinct_dev(const char* d_plain, uint64_t len, int k, int canon_mode, uint64_t min_count, int device, void* stream,
                            aix_distinct_t** out);
+/* K1 across GPUs: (key, count) pairs with repeated keys (what a rank holds after the all-to-all by key owner) -> the same kind
+ * of result object: keys ascending, counts of equal keys summed, counts >= min_count. n < 2^32. */
+int aix_merge_counts_dev(const uint64_t* d_keys, const uint64_t* d_counts, uint64_t n, uint64_t min_count, int device, void* stream,
+                         aix_distinct_t** out);
 int aix_distinct_size(const aix_distinct_t* r, uint64_t* n_out);
 int aix_distinct_copy_dev(const aix_distinct_t* r, uint64_t* d_keys, uint64_t* d_counts, void* stream);
 void aix_distinct_free(aix_distinct_t* r);
