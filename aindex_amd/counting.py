@@ -1,7 +1,7 @@
 """Distinct k-mer counting on the GPU — the K1 row (replaces the reference's `kmer_counter`).
 
-window codes (hand-written HIP kernel, csrc/aix_kernels.hip:k_window_codes) -> device radix sort +
-run-length (torch.unique -> rocPRIM). Output = the (k-mer, count) set the reference writes to
+window codes (hand-written HIP kernel, csrc/aix_kernels.hip:k_window_codes) -> rocPRIM radix sort + run-length inside
+the library (aix_count_distinct / aix_count_distinct_dev; buffers beyond 2^31 windows piece by piece). Output = the (k-mer, count) set the reference writes to
 ./output.txt (count_kmers.cpp:362-382), as arrays sorted by key; the reference's own order is
 "count descending, ties unspecified", so parity is on the set.
 """
