@@ -63,6 +63,11 @@ struct aix_index {
     unsigned long long* scratch13 = nullptr;   // code-ordered count table, lazily allocated
     void* work13 = nullptr;                    // partition workspace of the atomic-free counter (grow-only)
     uint64_t work13_bytes = 0;
+    // tiny host batches (a Python loop over index[kmer]): pinned, device-mapped staging so that a call is one memcpy into
+    // host memory, one launch and one synchronise — no hipMemcpy round trips
+    void* pin_in = nullptr;
+    void* pin_out[3] = {nullptr, nullptr, nullptr};
+    std::mutex small_mutex;
     hipEvent_t work13_done = nullptr;          // recorded behind every counting call: the next one (any stream) waits for it before touching the workspace
     uint64_t device_bytes = 0;
     bool canonical_only = false;
@@ -204,6 +209,8 @@ static void destroy(aix_index* h) {
     if (h->scratch13) (void)hipFree(h->scratch13);
     if (h->work13) (void)hipFree(h->work13);
     if (h->work13_done) (void)hipEventDestroy(h->work13_done);
+    if (h->pin_in) (void)hipHostFree(h->pin_in);
+    for (void* p : h->pin_out) if (p) (void)hipHostFree(p);
     delete h;
 }
 
@@ -676,12 +683,47 @@ extern "C" int aix_synth_reads_dev(uint64_t seed, const char* d_genome, uint64_t
 // host-pointer twins: stage through HBM in bounded chunks, run the same kernels, copy back
 // ---------------------------------------------------------------------------------------------
 static constexpr uint64_t kChunk = 1ull << 26;   // queries per staging chunk (64 Mi)
+static constexpr uint64_t kSmall = 4096;         // up to here a host batch goes through the pinned, device-mapped staging of the handle
+
+static int ensure_pinned(aix_index_t* h) {
+    if (h->pin_in) return AIX_OK;
+    void* in = nullptr;
+    if (hipHostMalloc(&in, kSmall * 23 + 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return AIX_ERR_NOMEM; }
+    for (int j = 0; j < 3; ++j)
+        if (hipHostMalloc(&h->pin_out[j], kSmall * 8, hipHostMallocMapped) != hipSuccess) {
+            (void)hipGetLastError();
+            for (int i = 0; i < j; ++i) { (void)hipHostFree(h->pin_out[i]); h->pin_out[i] = nullptr; }
+            (void)hipHostFree(in);
+            return AIX_ERR_NOMEM;
+        }
+    memset(in, '\n', kSmall * 23 + 64);
+    h->pin_in = in;
+    return AIX_OK;
+}
 
 template <typename F>
 static int chunked_ascii(aix_index_t* h, const char* kmers, uint64_t N, uint32_t out_elem_bytes[3], void* outs[3], F&& call) {
     if (!h || (N && !kmers)) return AIX_ERR_ARG;
     if (N == 0) return AIX_OK;
     DevGuard g(h->device);
+    if (N <= kSmall) {                                     // latency path: the kernel reads the queries from, and writes the answers to, host memory
+        std::lock_guard<std::mutex> lk(h->small_mutex);
+        if (ensure_pinned(h) == AIX_OK) {
+            void *din = nullptr, *dout[3] = {nullptr, nullptr, nullptr};
+            hipError_t e = hipHostGetDevicePointer(&din, h->pin_in, 0);
+            for (int j = 0; j < 3 && e == hipSuccess; ++j) e = hipHostGetDevicePointer(&dout[j], h->pin_out[j], 0);
+            if (e == hipSuccess) {
+                memcpy(h->pin_in, kmers, N * h->k);
+                int st = call((const char*)din, N, dout[0], dout[1], dout[2]);
+                if (st) return st;
+                HIPCHK(hipStreamSynchronize(0));
+                for (int j = 0; j < 3; ++j)
+                    if (outs[j]) memcpy(outs[j], h->pin_out[j], N * out_elem_bytes[j]);
+                return AIX_OK;
+            }
+            (void)hipGetLastError();
+        }
+    }
     const uint64_t k = h->k, chunk = std::min<uint64_t>(N, kChunk);
     DevBuf dq, d0, d1, d2;
     HIPCHK(dq.alloc(chunk * k + 8));
