@@ -619,6 +619,60 @@ def test_positions_and_reads_access_golden(gold, small23_prefix, tmp_path):
     assert st["non_zero_kmers"] + st["zero_kmers"] == st["total_kmers"] and abs(st["avg_tf"] - want_tf[want_tf > 0].mean()) < 1e-9
 
 
+def test_concurrent_host_calls_one_handle(canon_case, ix13):
+    """ctypes drops the GIL inside the library: four threads hammer ONE 23-mer handle (tiny and large lookups, coverage,
+    positions fill, counting) and one 13-mer handle (counting, lookups) plus the handle-less K1 call at the same time; every
+    answer must equal the answer of the same call made alone. Exercises the per-handle staging, the scratch pool, the
+    counting workspace and its cross-call ordering."""
+    import threading
+    from aindex_amd import counting
+    ix = canon_case["ix"]
+    g = canon_case["genome"]
+    q_big = mixed_queries(g, 200_000, 31)
+    q_small = q_big[:7].copy()
+    asc = synth.genome_ascii(23, 300_000)
+    reads = synth.reads_plain(46, asc, 3000, 150, rc_fraction_half=True, n_rate_ppm=1000).tobytes()
+    seqs = [reads[i * 151: i * 151 + 150] for i in range(40)]
+    want = {
+        "big": ix.tf_ascii(q_big), "small": ix.tf_ascii(q_small), "cov": ix.coverage(seqs, 0), "pos": ix.positions_fill(reads),
+        "c23": ix.count23_fixed(reads, _lib.FMT_PLAIN, _lib.CANON_TRUE_RC), "c13": ix13.count13(reads, _lib.FMT_PLAIN),
+        "k1": counting.count_distinct(reads, 23, _lib.CANON_TRUE_RC, 1, fmt=_lib.FMT_PLAIN),
+    }
+    errors = []
+
+    def worker(which):
+        try:
+            for it in range(6):
+                for name in which:
+                    if name == "big":
+                        ok = np.array_equal(ix.tf_ascii(q_big), want["big"])
+                    elif name == "small":
+                        ok = all(np.array_equal(ix.tf_ascii(q_small), want["small"]) for _ in range(50))
+                    elif name == "cov":
+                        ok = all(np.array_equal(a, b) for a, b in zip(ix.coverage(seqs, 0), want["cov"]))
+                    elif name == "pos":
+                        ind, pos = ix.positions_fill(reads)
+                        ok = np.array_equal(ind, want["pos"][0]) and np.array_equal(pos, want["pos"][1])
+                    elif name == "c23":
+                        ok = np.array_equal(ix.count23_fixed(reads, _lib.FMT_PLAIN, _lib.CANON_TRUE_RC), want["c23"])
+                    elif name == "c13":
+                        ok = np.array_equal(ix13.count13(reads, _lib.FMT_PLAIN), want["c13"])
+                    else:
+                        k, c = counting.count_distinct(reads, 23, _lib.CANON_TRUE_RC, 1, fmt=_lib.FMT_PLAIN)
+                        ok = np.array_equal(k, want["k1"][0]) and np.array_equal(c, want["k1"][1])
+                    if not ok:
+                        errors.append((name, it))
+        except Exception as e:                       # noqa: BLE001
+            errors.append((which, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(w,)) for w in (("big", "small", "cov"), ("pos", "small", "c23"), ("c13", "k1", "small"), ("k1", "pos", "big", "c13"))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
+
+
 def test_tools_cli(gold, small23_prefix, tmp_path):
     from aindex_amd import tools
     out = str(tmp_path / "o")
