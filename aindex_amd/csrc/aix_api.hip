@@ -68,6 +68,7 @@ struct aix_index {
     void* pin_in = nullptr;
     void* pin_out[3] = {nullptr, nullptr, nullptr};
     std::mutex small_mutex;
+    hipStream_t small_stream = nullptr;
     hipEvent_t work13_done = nullptr;          // recorded behind every counting call: the next one (any stream) waits for it before touching the workspace
     uint64_t device_bytes = 0;
     bool canonical_only = false;
@@ -209,6 +210,7 @@ static void destroy(aix_index* h) {
     if (h->scratch13) (void)hipFree(h->scratch13);
     if (h->work13) (void)hipFree(h->work13);
     if (h->work13_done) (void)hipEventDestroy(h->work13_done);
+    if (h->small_stream) (void)hipStreamDestroy(h->small_stream);
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     for (void* p : h->pin_out) if (p) (void)hipHostFree(p);
     delete h;
@@ -714,9 +716,10 @@ static int chunked_ascii(aix_index_t* h, const char* kmers, uint64_t N, uint32_t
             for (int j = 0; j < 3 && e == hipSuccess; ++j) e = hipHostGetDevicePointer(&dout[j], h->pin_out[j], 0);
             if (e == hipSuccess) {
                 memcpy(h->pin_in, kmers, N * h->k);
-                int st = call((const char*)din, N, dout[0], dout[1], dout[2]);
+                if (!h->small_stream && hipStreamCreateWithFlags(&h->small_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); h->small_stream = nullptr; }
+                int st = call((const char*)din, N, dout[0], dout[1], dout[2], (void*)h->small_stream);   // own stream: no implicit ordering with the null stream
                 if (st) return st;
-                HIPCHK(hipStreamSynchronize(0));
+                HIPCHK(hipStreamSynchronize(h->small_stream));
                 for (int j = 0; j < 3; ++j)
                     if (outs[j]) memcpy(outs[j], h->pin_out[j], N * out_elem_bytes[j]);
                 return AIX_OK;
@@ -733,7 +736,7 @@ static int chunked_ascii(aix_index_t* h, const char* kmers, uint64_t N, uint32_t
     for (uint64_t lo = 0; lo < N; lo += chunk) {
         const uint64_t m = std::min(chunk, N - lo);
         HIPCHK(hipMemcpy(dq.p, kmers + lo * k, m * k, hipMemcpyHostToDevice));
-        int st = call((const char*)dq.p, m, d0.p, d1.p, d2.p);
+        int st = call((const char*)dq.p, m, d0.p, d1.p, d2.p, nullptr);
         if (st) return st;
         HIPCHK(hipStreamSynchronize(0));
         for (int j = 0; j < 3; ++j)
@@ -749,8 +752,8 @@ extern "C" int aix_tf_batch_ascii(aix_index_t* h, const char* kmers, uint64_t N,
     if (empty23(h)) { memset(out, 0, 4 * N); return AIX_OK; }
     uint32_t eb[3] = {4, 0, 0};
     void* outs[3] = {out, nullptr, nullptr};
-    return chunked_ascii(h, kmers, N, eb, outs, [&](const char* dq, uint64_t m, void* a, void*, void*) {
-        return aix_tf_batch_ascii_dev(h, dq, m, (uint32_t*)a, nullptr);
+    return chunked_ascii(h, kmers, N, eb, outs, [&](const char* dq, uint64_t m, void* a, void*, void*, void* st) {
+        return aix_tf_batch_ascii_dev(h, dq, m, (uint32_t*)a, st);
     });
 }
 extern "C" int aix_hash_batch_ascii(aix_index_t* h, const char* kmers, uint64_t N, uint64_t* out) {
@@ -759,8 +762,8 @@ extern "C" int aix_hash_batch_ascii(aix_index_t* h, const char* kmers, uint64_t 
     if (empty23(h)) return AIX_ERR_UNSUPPORTED;
     uint32_t eb[3] = {8, 0, 0};
     void* outs[3] = {out, nullptr, nullptr};
-    return chunked_ascii(h, kmers, N, eb, outs, [&](const char* dq, uint64_t m, void* a, void*, void*) {
-        return aix_hash_batch_ascii_dev(h, dq, m, (uint64_t*)a, nullptr);
+    return chunked_ascii(h, kmers, N, eb, outs, [&](const char* dq, uint64_t m, void* a, void*, void*, void* st) {
+        return aix_hash_batch_ascii_dev(h, dq, m, (uint64_t*)a, st);
     });
 }
 extern "C" int aix_kid_strand_batch_ascii(aix_index_t* h, const char* kmers, uint64_t N, uint64_t* kid_out, uint8_t* strand_out) {
@@ -772,8 +775,8 @@ extern "C" int aix_kid_strand_batch_ascii(aix_index_t* h, const char* kmers, uin
     }
     uint32_t eb[3] = {8, 1, 0};
     void* outs[3] = {kid_out, strand_out, nullptr};
-    return chunked_ascii(h, kmers, N, eb, outs, [&](const char* dq, uint64_t m, void* a, void* b, void*) {
-        return aix_kid_strand_batch_ascii_dev(h, dq, m, kid_out ? (uint64_t*)a : nullptr, strand_out ? (uint8_t*)b : nullptr, nullptr);
+    return chunked_ascii(h, kmers, N, eb, outs, [&](const char* dq, uint64_t m, void* a, void* b, void*, void* st) {
+        return aix_kid_strand_batch_ascii_dev(h, dq, m, kid_out ? (uint64_t*)a : nullptr, strand_out ? (uint8_t*)b : nullptr, st);
     });
 }
 extern "C" int aix_tf_both_batch_ascii(aix_index_t* h, const char* kmers, uint64_t N, uint64_t* fwd_out, uint64_t* rc_out) {
@@ -784,8 +787,8 @@ extern "C" int aix_tf_both_batch_ascii(aix_index_t* h, const char* kmers, uint64
     }
     uint32_t eb[3] = {8, 8, 0};
     void* outs[3] = {fwd_out, rc_out, nullptr};
-    return chunked_ascii(h, kmers, N, eb, outs, [&](const char* dq, uint64_t m, void* a, void* b, void*) {
-        return aix_tf_both_batch_ascii_dev(h, dq, m, fwd_out ? (uint64_t*)a : nullptr, rc_out ? (uint64_t*)b : nullptr, nullptr);
+    return chunked_ascii(h, kmers, N, eb, outs, [&](const char* dq, uint64_t m, void* a, void* b, void*, void* st) {
+        return aix_tf_both_batch_ascii_dev(h, dq, m, fwd_out ? (uint64_t*)a : nullptr, rc_out ? (uint64_t*)b : nullptr, st);
     });
 }
 extern "C" int aix_tf_total_batch_ascii(aix_index_t* h, const char* kmers, uint64_t N, uint64_t* out) {
@@ -793,8 +796,8 @@ extern "C" int aix_tf_total_batch_ascii(aix_index_t* h, const char* kmers, uint6
     if (empty23(h)) { memset(out, 0, 8 * N); return AIX_OK; }
     uint32_t eb[3] = {8, 0, 0};
     void* outs[3] = {out, nullptr, nullptr};
-    return chunked_ascii(h, kmers, N, eb, outs, [&](const char* dq, uint64_t m, void* a, void*, void*) {
-        return aix_tf_total_batch_ascii_dev(h, dq, m, (uint64_t*)a, nullptr);
+    return chunked_ascii(h, kmers, N, eb, outs, [&](const char* dq, uint64_t m, void* a, void*, void*, void* st) {
+        return aix_tf_total_batch_ascii_dev(h, dq, m, (uint64_t*)a, st);
     });
 }
 
