@@ -27,6 +27,27 @@ def _enc(s) -> bytes:
     return s.encode("latin-1") if isinstance(s, str) else bytes(s)
 
 
+_PYFAST = False
+
+
+def _pyfast():
+    """The optional CPython helper built next to the library (csrc/aix_pyfast.c); None when it is not there."""
+    global _PYFAST
+    if _PYFAST is False:
+        _PYFAST = None
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "_aix_pyfast.so")
+        if os.path.exists(path):
+            try:
+                import importlib.util
+                spec = importlib.util.spec_from_file_location("_aix_pyfast", path)
+                mod = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(mod)
+                _PYFAST = mod
+            except Exception:                                  # noqa: BLE001 — host glue only, the Python path is equivalent
+                _PYFAST = None
+    return _PYFAST
+
+
 class AindexWrapper:
     def __init__(self, device: int = 0):
         self._device = device
@@ -183,6 +204,12 @@ class AindexWrapper:
     @staticmethod
     def _join_fixed(kmers, k: int):
         """One bytes object of len(kmers)*k bytes when every item is a k-character str/bytes, else None."""
+        fast = _pyfast()
+        if fast is not None:
+            flat = fast.join_fixed(kmers, k)                     # C loop over the list: no intermediate str / bytes objects
+            if flat is not None or not kmers:
+                return flat
+            # not all-ASCII k-character items: let the exact Python rules below decide (latin-1 characters are still one byte)
         try:
             if isinstance(kmers[0], str):
                 flat = "".join(kmers).encode("latin-1")
