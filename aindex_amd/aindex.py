@@ -358,9 +358,11 @@ class AIndex:
             return self._index_to_13mer, tf
         if self.n_kmers == 0:
             raise RuntimeError("23-mer index not properly loaded")
-        kmers = [self.get_kmer_by_kid(kid) for kid in range(self.n_kmers)]
-        tf = np.array(self.get_tf_values(kmers), dtype=np.uint64)
-        return (lambda i: kmers[i]), tf
+        from . import synth
+        codes = self._wrapper._checker() & np.uint64((1 << 46) - 1)                    # get_kmer_by_kid(kid) = decode of checker[kid]
+        kmers = synth.decode_kmers(codes, 23)                                          # (n, 23) uint8: no Python strings until one is yielded
+        tf = self.get_tf_values_array(kmers).astype(np.uint64)                         # get_tf_value(kmer) for every kid: ONE batch lookup
+        return (lambda i: bytes(kmers[i]).decode()), tf
 
     def iter_kmers_by_frequency(self, min_tf: int = 1, max_kmers: Optional[int] = None, kmer_type: str = "auto"):
         if not self._loaded:
