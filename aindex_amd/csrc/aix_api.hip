@@ -69,6 +69,7 @@ struct aix_index {
     void* pin_out[3] = {nullptr, nullptr, nullptr};
     std::mutex small_mutex;
     hipStream_t small_stream = nullptr;
+    void* pin_cov = nullptr;                   // pinned, device-mapped staging of small coverage requests (kCovPin bytes)
     hipEvent_t work13_done = nullptr;          // recorded behind every counting call: the next one (any stream) waits for it before touching the workspace
     uint64_t device_bytes = 0;
     bool canonical_only = false;
@@ -212,6 +213,7 @@ static void destroy(aix_index* h) {
     if (h->work13_done) (void)hipEventDestroy(h->work13_done);
     if (h->small_stream) (void)hipStreamDestroy(h->small_stream);
     if (h->pin_in) (void)hipHostFree(h->pin_in);
+    if (h->pin_cov) (void)hipHostFree(h->pin_cov);
     for (void* p : h->pin_out) if (p) (void)hipHostFree(p);
     delete h;
 }
@@ -852,6 +854,32 @@ extern "C" int aix_coverage_batch(aix_index_t* h, const char* seqs, const uint64
     if (ototal == 0) return AIX_OK;
     if (empty23(h)) { memset(out + obase, 0, 4 * ototal); return AIX_OK; }
     DevGuard g(h->device);
+    // latency path (one read, one contig window...): sequences, offsets and the profile live in pinned, device-mapped memory
+    constexpr uint64_t kCovSeq = 128u << 10, kCovM = 1024, kCovPin = kCovSeq + 64 + 2 * 8 * (kCovM + 1) + 4 * kCovSeq;
+    if (total <= kCovSeq && M <= kCovM && ototal <= kCovSeq) {
+        std::lock_guard<std::mutex> lk(h->small_mutex);
+        if (!h->pin_cov && hipHostMalloc(&h->pin_cov, kCovPin, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); h->pin_cov = nullptr; }
+        void* dbase = nullptr;
+        if (h->pin_cov && hipHostGetDevicePointer(&dbase, h->pin_cov, 0) == hipSuccess) {
+            if (!h->small_stream && hipStreamCreateWithFlags(&h->small_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); h->small_stream = nullptr; }
+            char* hp = (char*)h->pin_cov;
+            uint64_t* hoffs = (uint64_t*)(hp + kCovSeq + 64);
+            uint64_t* hooffs = hoffs + (kCovM + 1);
+            uint32_t* hout = (uint32_t*)(hooffs + (kCovM + 1));
+            memcpy(hp, seqs + base, total);
+            memset(hp + total, '\n', 8);
+            for (uint64_t i = 0; i <= M; ++i) { hoffs[i] = offs[i] - base; hooffs[i] = out_offs[i] - obase; }
+            memset(hout, 0, 4 * ototal);
+            char* dp = (char*)dbase;
+            int st = aix_coverage_batch_dev(h, dp, (const uint64_t*)(dp + ((char*)hoffs - hp)), M, total, cutoff, (uint32_t*)(dp + ((char*)hout - hp)),
+                                            (const uint64_t*)(dp + ((char*)hooffs - hp)), (void*)h->small_stream);
+            if (st) return st;
+            HIPCHK(hipStreamSynchronize(h->small_stream));
+            memcpy(out + obase, hout, 4 * ototal);
+            return AIX_OK;
+        }
+        (void)hipGetLastError();
+    }
     DevBuf ds, doffs, dooffs, dout;
     HIPCHK(ds.alloc(total + 8));
     HIPCHK(doffs.alloc((M + 1) * 8));
