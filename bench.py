@@ -129,7 +129,14 @@ def cpu_baseline_lookup23(ix, pf, q_sample_np, gpu_sample, tmpdir):
         so, se = os.dup(1), os.dup(2)
         os.dup2(devnull, 1); os.dup2(devnull, 2)              # the reference logs progress bars to stdout/stderr
         try:
-            w.load_from_prefix_23mer(prefix)
+            t = time.perf_counter(); w.load_from_prefix_23mer(prefix); t_ref_load = time.perf_counter() - t
+            from aindex_amd.engine import Index as _Index
+            t = time.perf_counter()
+            with _Index.open_23(prefix + ".pf", prefix + ".tf.bin", prefix + ".kmers.bin", ix.device) as ix2:
+                t_our_load = time.perf_counter() - t
+                assert ix2.n == ix.n
+            res["index_load_s"] = {"reference": t_ref_load, "ours": t_our_load,
+                                   "note": "load_from_prefix_23mer of the same three files (P2: hash.cpp:367-450 reads checker and tf element by element); ours = mmap + upload + record build in HBM"}
             sref = min(s, 5_000_000)
             qs = [bytes(x).decode() for x in q_sample_np[: sref * 23].reshape(-1, 23)]
             t = time.perf_counter(); got = w.get_tf_values(qs); dt = time.perf_counter() - t
@@ -444,6 +451,8 @@ def main():
             s = min(a.cpu_sample, a.queries)
             qs = q[: s * 23].cpu().numpy()
             cb = cpu_baseline_lookup23(ix, pf, qs, res[:s].cpu().numpy().view(np.uint32), os.path.join(cache, "cpu"))
+            if "index_load_s" in cb:
+                out["index_load_s"] = cb.pop("index_load_s")
             out["cpu_baseline"] = cb.get("reference", cb["port_1t"])
             out["cpu_baseline_extra"] = {k: v for k, v in cb.items()}
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
