@@ -329,6 +329,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather-probe", action="store_true", help="skip the live random-read roofline measurement")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary counting measurement of the default workload")
+    ap.add_argument("--reads13", type=int, default=10_000_000, help="reads per rank and step of the secondary 13-mer counting measurement (configs[1])")
     ap.add_argument("--reads23", type=int, default=10_000_000, help="reads per rank and step of the secondary counting measurement (config 4 has 25 M per GPU at N = 8)")
     ap.add_argument("--no-fastpath", action="store_true", help="force the reference's two-probe order")
     ap.add_argument("--no-fingerprint", action="store_true", help="disable the 4-bit fingerprint filter")
@@ -440,12 +441,36 @@ def main():
                     adist.all_reduce_sum_(tfh)
                 w23, k23, _ = timed_steps(step23, 3, 1, dev)
                 total = int(tfh.to(torch.int64).sum().item())
+                ar23, _, _ = timed_steps(lambda: adist.all_reduce_sum_(tfh), 3, 1, dev) if world > 1 else (0.0, 0.0, [])
                 sec["count23_fixed_mphf"] = {"metric": "reads_per_sec_23mer_count_fixed_mphf", "value": world * a.reads23 * 3 / w23, "unit": "reads/s",
-                                             "reads_per_step_per_gpu": a.reads23, "ms_per_step": w23 / 3 * 1e3, "windows_counted_all_ranks": total,
+                                             "reads_per_step_per_gpu": a.reads23, "ms_per_step": w23 / 3 * 1e3, "allreduce_ms_of_it": ar23 / 3 * 1e3,
+                                             "windows_counted_all_ranks": total,
                                              "collective": "all_reduce(sum) of int32 tf[n]" if world > 1 else "none (1 rank)"}
                 del reads, tfh
             except Exception as e:  # pragma: no cover
                 sec["count23_fixed_mphf"] = {"error": f"{type(e).__name__}: {e}"}
+            # BASELINE configs[1]: 13-mer dense 4^13 table, 10 M reads per rank, u64 table merged by one all-reduce
+            try:
+                from aindex_amd.engine import Index as _Index13
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                from pf13 import pf13_path
+                ix13 = _Index13.open_13(pf13_path(), None, dev)
+                g13 = engine.synth_genome_t(13, 4_000_000, dev)
+                reads13 = engine.synth_reads_t(14, g13, a.reads13, 150, n_rate_ppm=1000, first_read=rank * a.reads13)
+                tf13 = torch.empty(4 ** 13, dtype=torch.int64, device=f"cuda:{dev}")
+                def step13():
+                    ix13.count13_t(reads13, tf13)
+                    adist.all_reduce_sum_(tf13)
+                w13, k13, _ = timed_steps(step13, 3, 1, dev)
+                ar13, _, _ = timed_steps(lambda: adist.all_reduce_sum_(tf13), 3, 1, dev) if world > 1 else (0.0, 0.0, [])
+                sec["count13_dense"] = {"metric": "reads_per_sec_13mer_count", "value": world * a.reads13 * 3 / w13, "unit": "reads/s",
+                                        "reads_per_step_per_gpu": a.reads13, "ms_per_step": w13 / 3 * 1e3, "allreduce_ms_of_it": ar13 / 3 * 1e3,
+                                        "windows_counted_all_ranks": int(tf13.sum().item()),
+                                        "collective": "all_reduce(sum) of int64 tf[4^13]" if world > 1 else "none (1 rank)"}
+                ix13.close()
+                del reads13, tf13, g13
+            except Exception as e:  # pragma: no cover
+                sec["count13_dense"] = {"error": f"{type(e).__name__}: {e}"}
             out["secondary"] = sec
         if rank == 0 and world == 1 and not a.no_cpu_baseline:
             s = min(a.cpu_sample, a.queries)
