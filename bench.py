@@ -462,10 +462,11 @@ def main():
                     ix13.count13_t(reads13, tf13)
                     adist.all_reduce_sum_(tf13)
                 w13, k13, _ = timed_steps(step13, 3, 1, dev)
+                total13 = int(tf13.sum().item())
                 ar13, _, _ = timed_steps(lambda: adist.all_reduce_sum_(tf13), 3, 1, dev) if world > 1 else (0.0, 0.0, [])
                 sec["count13_dense"] = {"metric": "reads_per_sec_13mer_count", "value": world * a.reads13 * 3 / w13, "unit": "reads/s",
                                         "reads_per_step_per_gpu": a.reads13, "ms_per_step": w13 / 3 * 1e3, "allreduce_ms_of_it": ar13 / 3 * 1e3,
-                                        "windows_counted_all_ranks": int(tf13.sum().item()),
+                                        "windows_counted_all_ranks": total13,
                                         "collective": "all_reduce(sum) of int64 tf[4^13]" if world > 1 else "none (1 rank)"}
                 ix13.close()
                 del reads13, tf13, g13
