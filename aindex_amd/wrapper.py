@@ -114,6 +114,10 @@ class AindexWrapper:
         a = np.loadtxt(index_file, dtype=np.uint64, ndmin=2) if os.path.getsize(index_file) else np.zeros((0, 3), np.uint64)
         self._ridx_rid, self._ridx_start, self._ridx_end = a[:, 0].copy(), a[:, 1].copy(), a[:, 2].copy()
         self.n_reads = int(a.shape[0])
+        # the reference scans its interval list linearly for every query (python_wrapper.cpp:66-74). When the intervals are
+        # sorted and disjoint — what compute_reads writes — the first match of that scan is found by bisection instead.
+        st, en = self._ridx_start, self._ridx_end
+        self._ridx_sorted = bool(a.shape[0] == 0 or (np.all(en >= st) and np.all(st[1:] > en[:-1])))
 
     def load_reads(self, reads_file: str):
         """:281-322 — mmap the reads file and read the sibling `.ridx`."""
@@ -174,6 +178,9 @@ class AindexWrapper:
             return None
         # IntervalTree::query(pos, pos + 1) of python_wrapper.cpp:66-74: first interval in file order with
         # start <= pos + 1 and (end + 1) >= pos
+        if getattr(self, "_ridx_sorted", False):
+            i0 = int(np.searchsorted(self._ridx_end, np.uint64(max(pos - 1, 0)), side="left"))   # first interval with end + 1 >= pos
+            return i0 if i0 < self.n_reads and int(self._ridx_start[i0]) <= pos + 1 else None
         hit = np.nonzero((self._ridx_start <= np.uint64(pos + 1)) & (self._ridx_end + np.uint64(1) >= np.uint64(pos)))[0]
         return int(hit[0]) if hit.shape[0] else None
 
