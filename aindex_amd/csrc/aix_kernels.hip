@@ -482,8 +482,8 @@ __global__ void __launch_bounds__(kBlock) k_count23_fixed(const IndexDev ix, con
     if (len < 23) return;
     const uint64_t nwin = len - 22;
     IndexDev ixn = ix;
-    ixn.use_fp = 0;               // windows of reads drawn from the indexed genome are hits: the filters only cost
-    ixn.early_exit = 0;
+    ixn.early_exit = 0;           // windows of reads drawn from the indexed genome are mostly hits: the parallel three-read evaluation; the
+                                  // fingerprint (same 16 bytes as the pairs) still spares the key-record read of a window that is NOT a key
     for (uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x; p < nwin; p += stride) {
         uint64_t w0, w1, w2;
         load23(buf + p, w0, w1, w2);
