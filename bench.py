@@ -540,7 +540,31 @@ def main():
         wall, kern_ms, _ = timed_steps(step, a.steps, a.warmup, dev)
         windows = a.reads * (150 - 22)
         achieved = (a.reads * 151 + windows * (100.0 + 4.0 + 8.0)) / (kern_ms * 1e-3) / 1e9
-        out.update({"metric": "reads_per_sec_23mer_count_fixed_mphf", "value": world * a.reads * a.steps / wall, "unit": "reads/s",
+        cb23 = None
+        if rank == 0 and world == 1 and not a.no_cpu_baseline:
+            # the reference has no tool for this composition (kmer_counter -> compute_index would re-derive the key set); the CPU
+            # path timed beside it is the C restatement of the same histogram (forward-then-rc MPHF probes per window), 1 thread
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as O
+            tmpd = os.path.join(cache, "cpu23c")
+            os.makedirs(tmpd, exist_ok=True)
+            prefix = os.path.join(tmpd, "c23")
+            open(prefix + ".pf", "wb").write(pf)
+            ix.tf_array().tofile(prefix + ".tf.bin")
+            ix.checker_array().tofile(prefix + ".kmers.bin")
+            orc = O.OracleIndex23.from_prefix(prefix)
+            ns = min(a.reads, 100_000)
+            sample = reads[: ns * 151]
+            gpu_s = torch.zeros(ix.n, dtype=torch.int32, device=f"cuda:{dev}")
+            ix.count23_fixed_t(sample, _lib.CANON_TRUE_RC, gpu_s)
+            t0 = time.perf_counter(); want = orc.count23_fixed(sample.cpu().numpy().tobytes(), False, 2); dt = time.perf_counter() - t0
+            assert np.array_equal(want, gpu_s.cpu().numpy().view(np.uint32)), "CPU port and GPU disagree on the sample"
+            cb23 = {"value": ns / dt, "unit": "reads/s", "cores": 1, "kind": "port", "sample": f"first {ns} reads of the batch"}
+            del orc
+            for f in (".pf", ".tf.bin", ".kmers.bin"):
+                os.remove(prefix + f)
+        out.update({**({"cpu_baseline": cb23} if cb23 else {}),
+                    "metric": "reads_per_sec_23mer_count_fixed_mphf", "value": world * a.reads * a.steps / wall, "unit": "reads/s",
                     "ms_per_step": wall / a.steps * 1e3, "dtype": "u64",
                     "config": {"workload": "configs[3]: 23-mer histogram against a fixed MPHF, 150 bp reads, + all-reduce(sum) of tf[]",
                                "reads_per_step_per_gpu": a.reads, "index_keys": ix.n},
