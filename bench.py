@@ -673,11 +673,45 @@ def main():
         indices, pos = ix.positions_fill(host_bytes)
         host_dt = time.perf_counter() - t0
         assert np.array_equal(indices, indices_t.cpu().numpy().view(np.uint64)) and np.array_equal(pos, pos_t.cpu().numpy().view(np.uint64))
+        cbp = None
+        exe = os.path.join(ROOT, "oracle", "_ref", "compute_aindex")
+        if rank == 0 and world == 1 and not a.no_cpu_baseline and os.path.exists(exe):
+            # the reference's own tool (one thread: its multi-thread slot order is schedule dependent) on a sample of the same
+            # reads against the same index files; its .index.bin must equal ours byte for byte. Wall clock of the whole run
+            # (it loads the index first: ~1 s of the total).
+            import subprocess
+            tmpd = os.path.join(cache, "cpupos")
+            os.makedirs(tmpd, exist_ok=True)
+            prefix = os.path.join(tmpd, "p23")
+            open(prefix + ".pf", "wb").write(pf)
+            ix.tf_array().tofile(prefix + ".tf.bin")
+            ix.checker_array().tofile(prefix + ".kmers.bin")
+            ns = min(a.reads, 100_000)
+            sample = host_bytes[: ns * 151]
+            open(prefix + ".reads", "wb").write(sample)
+            try:
+                t0 = time.perf_counter()
+                subprocess.run([exe, prefix + ".reads", prefix + ".pf", prefix, "1", "23", prefix + ".tf.bin", prefix + ".kmers.bin", prefix + ".none.txt"],
+                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900, check=True)
+                dt_ref = time.perf_counter() - t0
+                ours_ind, ours_pos = ix.positions_fill(sample)
+                assert np.array_equal(np.fromfile(prefix + ".index.bin", dtype=np.uint64), ours_pos), "reference compute_aindex and GPU disagree on the sample"
+                assert np.array_equal(np.fromfile(prefix + ".indices.bin", dtype=np.uint64), ours_ind)
+                cbp = {"value": ns / dt_ref, "unit": "reads/s", "cores": 1, "kind": "reference",
+                       "sample": f"first {ns} reads of the batch through oracle/_ref/compute_aindex, 1 thread (wall clock incl. its index load and file output)"}
+            except Exception as e:
+                log(f"cpu_baseline: reference compute_aindex not usable ({type(e).__name__}: {e})")
+            for f in (".pf", ".tf.bin", ".kmers.bin", ".reads", ".index.bin", ".indices.bin"):
+                try:
+                    os.remove(prefix + f)
+                except OSError:
+                    pass
         windows = int(reads_t.numel() - 22)
         # bytes the fill asks for: 23+4 per window (probe: query bytes in, bucket out), 3 x 16 + 16 per probed window, and the
         # radix sort of (bucket, offset) pairs (4 passes x 16 B read + written), 8 B per placed offset
         achieved = (windows * (1.0 + 4.0 + 64.0 + 4 * 16.0) + 8.0 * int(indices[-1])) / (kern_ms * 1e-3) / 1e9
-        out.update({"metric": "reads_per_sec_positions_fill_23mer", "value": world * a.reads * a.steps / wall, "unit": "reads/s",
+        out.update({**({"cpu_baseline": cbp} if cbp else {}),
+                    "metric": "reads_per_sec_positions_fill_23mer", "value": world * a.reads * a.steps / wall, "unit": "reads/s",
                     "ms_per_step": wall / a.steps * 1e3, "dtype": "u64",
                     "config": {"workload": "A1+A2: positions index of 150 bp reads (resident in HBM) against the fixed 23-mer index",
                                "reads": a.reads, "windows": windows, "positions_total": int(indices[-1]), "filled": int((pos != 0).sum()),
