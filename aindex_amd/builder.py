@@ -68,3 +68,17 @@ def build_all_13mers_pf(path: str | None = None) -> bytes:
         with open(path, "wb") as f:
             f.write(img)
     return img
+
+
+def all_13mers_pf_path(path: str | None = None) -> str:
+    """Path of the all-13-mers `.pf` (22 MB, the 13-mer mode's fixed perfect hash; sha256 pinned in tests/golden/pf13.json),
+    built with build_all_13mers_pf on first use. Default location: <repo>/data/all_13mers.pf or $AIX_PF13."""
+    import os
+    if path is None:
+        path = os.environ.get("AIX_PF13") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "all_13mers.pf")
+    if not os.path.exists(path):
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        tmp = path + f".tmp{os.getpid()}"
+        build_all_13mers_pf(tmp)
+        os.replace(tmp, path)                       # several ranks may race here: each writes its own file, the rename is atomic
+    return path

@@ -452,8 +452,7 @@ def main():
             # BASELINE configs[1]: 13-mer dense 4^13 table, 10 M reads per rank, u64 table merged by one all-reduce
             try:
                 from aindex_amd.engine import Index as _Index13
-                sys.path.insert(0, os.path.join(ROOT, "tests"))
-                from pf13 import pf13_path
+                from aindex_amd.builder import all_13mers_pf_path as pf13_path
                 ix13 = _Index13.open_13(pf13_path(), None, dev)
                 g13 = engine.synth_genome_t(13, 4_000_000, dev)
                 reads13 = engine.synth_reads_t(14, g13, a.reads13, 150, n_rate_ppm=1000, first_read=rank * a.reads13)
@@ -485,8 +484,7 @@ def main():
 
     elif a.workload == "lookup13":
         from aindex_amd.engine import Index
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from pf13 import pf13_path
+        from aindex_amd.builder import all_13mers_pf_path as pf13_path
         ix = Index.open_13(pf13_path(), None, dev)
         g = engine.synth_genome_t(13, 4_000_000, dev)
         reads = engine.synth_reads_t(14, g, 1_000_000, 150, n_rate_ppm=1000)
@@ -507,8 +505,7 @@ def main():
 
     elif a.workload == "count13":
         from aindex_amd.engine import Index
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from pf13 import pf13_path
+        from aindex_amd.builder import all_13mers_pf_path as pf13_path
         ix = Index.open_13(pf13_path(), None, dev)
         g = engine.synth_genome_t(13, 4_000_000, dev)
         reads = engine.synth_reads_t(14, g, a.reads, 150, n_rate_ppm=1000, first_read=rank * a.reads)
@@ -613,8 +610,7 @@ def main():
 
     elif a.workload == "coverage13":
         from aindex_amd.engine import Index
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from pf13 import pf13_path
+        from aindex_amd.builder import all_13mers_pf_path as pf13_path
         ix = Index.open_13(pf13_path(), None, dev)
         g = engine.synth_genome_t(13, 4_000_000, dev)
         reads = engine.synth_reads_t(14, g, 1_000_000, 150, n_rate_ppm=1000)

@@ -8,11 +8,8 @@ PF13 = os.path.join(ROOT, "data", "all_13mers.pf")
 
 
 def pf13_path():
-    if not os.path.exists(PF13):
-        from aindex_amd import builder  # product MWHC builder (C++), bit-identical to the reference's
-        os.makedirs(os.path.dirname(PF13), exist_ok=True)
-        builder.build_all_13mers_pf(PF13)
-    return PF13
+    from aindex_amd import builder  # product MWHC builder (C++), bit-identical to the reference's
+    return builder.all_13mers_pf_path(PF13)
 
 
 def pf13_sha_ok():
