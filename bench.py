@@ -404,11 +404,18 @@ def main():
         line_gbs = (lines_per_query + 27.0 / 128.0) * 128.0 * a.queries / (kern_ms * 1e-3) / 1e9
         # the reference algorithm's bytes for the same queries (104 B forward hit, 204 B reverse hit, 200 B miss, + 27 B streamed)
         ref_bytes = 27.0 + (200.0 * (1.0 - hf) + 154.0 * hf)
-        out["roofline"].update({"achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_query": bytes_per_query,
+        # roofline.achieved follows the contract: SURVEY 8(d)'s per-query figure (the reference algorithm's bytes for this hit mix:
+        # 227 B on Q_rand) x queries / kernel time. The kernel answers with FEWER bytes than that figure (early exit: 1.16 records
+        # instead of two full evaluations), so the fraction can exceed 1; what it really asks for is under `reads_issued`, the
+        # HBM-side line traffic under `traffic` (PMC) / `line_traffic_estimate`, the random-read yardstick under `random_read`.
+        ref_gbs = ref_bytes * a.queries / (kern_ms * 1e-3) / 1e9
+        out["roofline"].update({"achieved": ref_gbs, "frac": ref_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_query": ref_bytes,
+                                "note": "SURVEY 8(d) bytes per query (reference algorithm) / kernel time; > peak because the early-exit evaluation "
+                                        "reads 1.16 records per absent query instead of two full MPHF evaluations — see reads_issued",
+                                "reads_issued": {"bytes_per_query": bytes_per_query, "GBps": achieved, "frac": achieved / HBM_PEAK_GBS,
+                                                 "note": "what this kernel actually requests, at SURVEY 8(d)'s per-access sizes"},
                                 "line_traffic_estimate": {"GBps": line_gbs, "frac_of_peak": line_gbs / HBM_PEAK_GBS,
-                                                          "note": "records read x 128-byte lines + streamed bytes, per second; the PMC figure is `traffic`"},
-                                "reference_algorithm_equivalent": {"bytes_per_query": ref_bytes, "GBps": ref_bytes * a.queries / (kern_ms * 1e-3) / 1e9,
-                                                                   "note": "what the reference's two-probe evaluation would have read for these queries"}})
+                                                          "note": "records read x 128-byte lines + streamed bytes, per second; the PMC figure is `traffic`"}})
         out["config"].update({"mphf_records_read_per_query": mphf_recs, "key_records_read_per_query": key_recs,
                               "completed_evaluations_per_query": completed, "records_read_per_query": lines_per_query})
         out["config"]["early_exit"] = not a.no_early_exit
@@ -495,13 +502,14 @@ def main():
         res = torch.empty(a.queries, dtype=torch.int32, device=f"cuda:{dev}")
         step = lambda: ix.tf_ascii_t(q, res)
         wall, kern_ms, _ = timed_steps(step, a.steps, a.warmup, dev)
-        bpq = 13.0 + 4.0 + 8.0      # our layout: one 8-byte read of the code-ordered table (+ streamed query/result)
+        bpq = 100.0 + 17.0          # one MPHF evaluation (92 B) + the 8-byte tf + 17 B streamed; ours: ONE 8-byte read of the code-ordered table
         achieved = bpq * a.queries / (kern_ms * 1e-3) / 1e9
         out.update({"metric": "kmer_lookups_per_sec_13mer_batch", "value": world * a.queries * a.steps / wall, "unit": "lookups/s",
                     "ms_per_step": wall / a.steps * 1e3, "dtype": "u64",
                     "config": {"workload": "13-mer dense table batch lookup, uniform-random 13-mers", "queries_per_step_per_gpu": a.queries},
                     "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                                 "traffic": None, "kernel": "k_lookup13_ascii", "kernel_ms": kern_ms}})
+                                 "traffic": None, "kernel": "k_lookup13_ascii", "kernel_ms": kern_ms, "algorithmic_bytes_per_query": bpq,
+                                 "reads_issued": {"bytes_per_query": 25.0, "GBps": 25.0 * a.queries / (kern_ms * 1e-3) / 1e9}}})
 
     elif a.workload == "count13":
         from aindex_amd.engine import Index
@@ -536,7 +544,7 @@ def main():
             adist.all_reduce_sum_(tf)
         wall, kern_ms, _ = timed_steps(step, a.steps, a.warmup, dev)
         windows = a.reads * (150 - 22)
-        achieved = (a.reads * 151 + windows * (100.0 + 4.0 + 8.0)) / (kern_ms * 1e-3) / 1e9
+        achieved = (a.reads * 151 + windows * (154.0 + 8.0)) / (kern_ms * 1e-3) / 1e9     # input + mean 154 B per hit (50/50 strands) + 8 B counter RMW
         cb23 = None
         if rank == 0 and world == 1 and not a.no_cpu_baseline:
             # the reference has no tool for this composition (kmer_counter -> compute_index would re-derive the key set); the CPU
