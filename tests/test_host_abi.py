@@ -117,3 +117,54 @@ def test_header_is_plain_c_and_links(tmp_path):
                            f"-L{libdir}", "-laindex_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.run([str(exe)], stdout=subprocess.PIPE, timeout=120).stdout.decode()
     assert "gfx950" in out
+
+
+# ------------------------------------------------------------------------------------------------
+# host-side glue of the Python mirrors (no GPU needed)
+# ------------------------------------------------------------------------------------------------
+def test_list_packing_helper_matches_python_rules():
+    """csrc/aix_pyfast.c (built next to the library) and the pure-Python path agree on what is a fixed-length batch."""
+    from aindex_amd import wrapper
+    f = wrapper.AindexWrapper._join_fixed
+    cases = [(["ACG", "TTT"], 3, b"ACGTTT"), ([b"ACG", "TTT"], 3, b"ACGTTT"), (("ACG",), 3, b"ACG"), (["AC", "TTTT"], 3, None),
+             (["ACG", 5], 3, None), (["AC\xe9"], 3, b"AC\xe9"), (["ACG", "TT€"], 3, None), (["ACGTACGTACGTA"] * 1000, 13, b"ACGTACGTACGTA" * 1000)]
+    for helper in (True, False):
+        saved = wrapper._PYFAST
+        if not helper:
+            wrapper._PYFAST = None                       # force the Python path
+        try:
+            if helper and wrapper._pyfast() is None:
+                pytest.skip("aix_pyfast not built")
+            for items, k, want in cases:
+                got = f(items, k)
+                # a list mixing str and bytes is packed by the helper and sent down the exact per-item path by the Python rules
+                assert got == want or (not helper and got is None and len({type(x) for x in items}) > 1), (helper, items)
+        finally:
+            wrapper._PYFAST = saved
+
+
+def test_read_interval_bisection_equals_linear_rule():
+    """get_rid / get_start: the bisection used for sorted, disjoint .ridx intervals returns what the reference's linear scan
+    (first interval with start <= pos + 1 and end + 1 >= pos, python_wrapper.cpp:66-74) returns, gaps and touching reads included."""
+    from aindex_amd.wrapper import AindexWrapper
+    for seed in range(4):
+        rng = np.random.default_rng(seed)
+        lens, gaps = rng.integers(1, 50, size=200), rng.integers(0, 3, size=200)
+        st = np.cumsum(np.concatenate([[0], (lens + gaps)[:-1]])).astype(np.uint64)
+        en = st + lens.astype(np.uint64) - np.uint64(1)
+        w = AindexWrapper.__new__(AindexWrapper)
+        w.aindex_loaded, w.n_reads = True, 200
+        w._ridx_rid, w._ridx_start, w._ridx_end = np.arange(200, dtype=np.uint64), st, en
+        for sorted_flag in (True, False):
+            w._ridx_sorted = sorted_flag
+            for pos in range(0, int(en[-1]) + 5):
+                hit = np.nonzero((st <= np.uint64(pos + 1)) & (en + np.uint64(1) >= np.uint64(pos)))[0]
+                assert w._interval(pos) == (int(hit[0]) if hit.shape[0] else None), (seed, sorted_flag, pos)
+
+
+def test_small_python_helpers():
+    from aindex_amd.aindex import AIndex, get_revcomp, hamming_distance
+    assert hamming_distance("ACGTN", "ACCTA") == 1 and hamming_distance("AAAA", "AAAT") == 1 and hamming_distance("", "A") == 0
+    assert get_revcomp("ACGTNacgtn~[]") == "[]~nacgtNACGT"
+    assert AIndex._index_to_13mer(None, 0) == "A" * 13 and AIndex._index_to_13mer(None, 4 ** 13 - 1) == "T" * 13
+    assert AIndex._index_to_13mer(None, 27) == "AAAAAAAAAACGT"
