@@ -32,3 +32,24 @@ def test_two_rank_gloo_counting_and_queries():
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     out = r.stdout.decode(errors="replace")
     assert r.returncode == 0 and "DIST_OK" in out, out[-3000:]
+
+
+def test_exchange_merge_single_process_and_owner_hash():
+    """Without a process group the exchange is the local merge alone; the owner hash is the splitmix64 finaliser (big-int check)."""
+    import torch
+    keys = torch.tensor([7, 3, 7, 2 ** 45 + 1, 3, 3], dtype=torch.int64)
+    counts = torch.tensor([1, 2, 3, 4, 5, 6], dtype=torch.int64)
+    k, c = adist.exchange_merge_counts(keys, counts, 1)
+    assert k.tolist() == [3, 7, 2 ** 45 + 1] and c.tolist() == [13, 4, 4]
+    k, c = adist.exchange_merge_counts(keys, counts, 5)
+    assert k.tolist() == [3] and c.tolist() == [13]
+
+    def sm(x):
+        m = (1 << 64) - 1
+        z = (x + 0x9E3779B97F4A7C15) & m
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+        return (z ^ (z >> 31)) >> 1
+    probe = torch.tensor([0, 1, 5, 4 ** 23 - 1, 123456789012, 2 ** 61], dtype=torch.int64)
+    for world in (2, 3, 8):
+        assert adist._owner_of(probe, world).tolist() == [sm(int(x)) % world for x in probe]
