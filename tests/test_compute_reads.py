@@ -31,3 +31,17 @@ def test_compute_reads_matches_reference(gold, tmp_path, name):
         else:
             assert not os.path.exists(prefix + ext)
     assert checked >= 1
+
+
+def test_tool_argument_contracts():
+    """Usage errors of the argv front ends return the reference's non-zero statuses without touching a GPU
+    (count_kmers13.cpp:546-566, count_kmers.cpp:394-414, compute_index.cpp:36-49, compute_aindex.cpp:30-63)."""
+    from aindex_amd import tools
+    assert tools.main([]) == 2 and tools.main(["no_such_tool"]) == 2
+    assert tools.main(["count_kmers13", "reads.fa"]) == 1
+    assert tools.main(["kmer_counter", "reads.fa", "23"]) == 1
+    assert tools.main(["compute_mphf_seq"]) == 1
+    assert tools.main(["compute_index", "a.dat", "a.pf", "prefix"]) == 1
+    assert tools.main(["compute_aindex", "r", "pf", "prefix", "1", "23"]) == 1
+    assert tools.main(["compute_aindex", "r", "pf", "prefix", "1", "13", "tf", "kmers.bin"]) == 1      # only k = 23
+    assert tools.main(["compute_reads", "a.fa", "-", "fasta"]) == 1
