@@ -533,6 +533,10 @@ def main():
                     **({"cpu_baseline": cb.get("reference", cb["port_mt"]), "cpu_baseline_extra": cb} if cb else {}),
                     "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                  "traffic": None, "kernel": "k_c13_split_chunked + directory sort + k_c13_hist_chunked (+ memset of the table)", "kernel_ms": kern_ms}})
+        tr = load_pmc_traffic("count13")
+        if tr and tr.get("reads_per_launch") == a.reads:
+            out["roofline"]["traffic"] = tr.get("bytes_per_launch")
+            out["roofline"]["traffic_source"] = tr.get("source")
 
     elif a.workload == "count23":
         ix, g, keys, counts, pf = build_index23(a.genome, rank, world, dev, cache)
