@@ -45,6 +45,7 @@ SIGNATURES = {
     "aix_version": (C.c_char_p, []),
     "aix_strerror": (C.c_char_p, [i32]),
     "aix_device_count": (i32, [C.POINTER(i32)]),
+    "aix_pf_check": (i32, [vp, u64, C.POINTER(u64 * 4)]),
     "aix_index_open_23": (i32, [C.c_char_p, C.c_char_p, C.c_char_p, i32, C.POINTER(vp)]),
     "aix_index_open_13": (i32, [C.c_char_p, C.c_char_p, i32, C.POINTER(vp)]),
     "aix_index_create_23": (i32, [vp, u64, vp, vp, u64, i32, C.POINTER(vp)]),

@@ -41,10 +41,20 @@ struct DevGuard {   // switch to the handle's device for the duration of a call,
     ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
 
-struct DevBuf {                     // per-call temporary from the scratch pool; every user synchronises before it goes out of scope
+struct DevBuf {                     // per-call temporary from the scratch pool, used on ONE stream (default: the null stream)
     void* p = nullptr;
+    hipStream_t st = nullptr;
+    DevBuf() = default;
+    explicit DevBuf(hipStream_t s) : st(s) {}
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    bool pooled = true;
     hipError_t alloc(uint64_t bytes) { return pool_alloc(&p, bytes ? bytes : 1); }
-    ~DevBuf() { if (p) { (void)hipDeviceSynchronize(); pool_free(p); } }   // whatever stream used it has drained
+    // one-shot staging (index load): straight from the driver and straight back, never parked in the scratch cache
+    hipError_t alloc_once(uint64_t bytes) { pooled = false; return hipMalloc(&p, bytes ? bytes : 1); }
+    // a block goes back to the pool idle: wait for the stream it was used on (not for the whole device — other handles and
+    // other host threads keep running; error paths leave through here too)
+    ~DevBuf() { if (p) { (void)hipStreamSynchronize(st); if (pooled) pool_free(p); else (void)hipFree(p); } }
 };
 
 struct aix_index {
@@ -72,6 +82,7 @@ struct aix_index {
     void* pin_cov = nullptr;                   // pinned, device-mapped staging of small coverage requests (kCovPin bytes)
     hipEvent_t work13_done = nullptr;          // recorded behind every counting call: the next one (any stream) waits for it before touching the workspace
     uint64_t device_bytes = 0;
+    bool perm13_bijective = false;             // 13-mer: code -> mphf slot is a bijection of [0, 4^13) (true for the all-13-mers .pf)
     bool canonical_only = false;
     bool canonical_fastpath = true;
     bool has_fp = false;
@@ -158,16 +169,33 @@ struct MappedFile {
     ~MappedFile() { if (p) munmap((void*)p, len); }
 };
 
+// .pf header checks shared by every entry point that takes a .pf image (host only)
+extern "C" int aix_pf_check(const void* pf_bytes, uint64_t pf_len, uint64_t hdr_out[4]) {
+    if (!pf_bytes) return AIX_ERR_ARG;
+    if (pf_len < 32) return AIX_ERR_FORMAT;
+    uint64_t hdr[4];
+    memcpy(hdr, pf_bytes, 32);
+    const uint64_t n = hdr[0], D = hdr[1], B = hdr[3];
+    // mphf.hpp:26,99-113: B = 3 * hash_domain bit-pairs. A header whose product wraps (D = 0x5555555555555556, B = 2) or whose
+    // domain needs more than 32-bit node ids (the builder's own limit) would index the record table far out of bounds on the
+    // device, so it is refused here, before anything is uploaded.
+    // (D = 0 is the MPHF of an empty key set: mphf.hpp:26 gives (ceil(0 * 1.23) + 2) / 3 = 0; nothing is ever evaluated on it.)
+    if (D > 0xFFFFFFFFull / 3) return AIX_ERR_FORMAT;
+    if (B != 3 * D) return AIX_ERR_FORMAT;
+    if (n > B) return AIX_ERR_FORMAT;
+    const uint64_t W = (B + 31) / 32, R = (B + 511) / 512;
+    if (pf_len < 32 + 8 * (W + R)) return AIX_ERR_FORMAT;
+    if (hdr_out) memcpy(hdr_out, hdr, 32);
+    return AIX_OK;
+}
+
 // parse a .pf image (mphf.hpp:99-113) and lay it out as BvRec records in HBM
 static int upload_mphf(aix_index* h, const uint8_t* pf, uint64_t len) {
-    if (len < 32) return AIX_ERR_FORMAT;
     uint64_t hdr[4];
-    memcpy(hdr, pf, 32);
+    const int chk = aix_pf_check(pf, len, hdr);
+    if (chk) return chk;
     h->mphf_n = hdr[0]; h->D = hdr[1]; h->seed = hdr[2]; h->B = hdr[3];
-    if (h->B != 3 * h->D) return AIX_ERR_FORMAT;
     h->W = (h->B + 31) / 32;
-    const uint64_t R = (h->B + 511) / 512;
-    if (len < 32 + 8 * (h->W + R)) return AIX_ERR_FORMAT;
     if (h->mphf_n >> 32) return AIX_ERR_UNSUPPORTED;          // 32-bit rank prefixes
     const uint64_t* words = (const uint64_t*)(pf + 32);
     const uint64_t nrec = (h->B + 15) / 16;                      // two records per 64-bit word
@@ -256,8 +284,8 @@ extern "C" int aix_index_create_23(const void* pf_bytes, uint64_t pf_len, const 
     st = upload_mphf(h, (const uint8_t*)pf_bytes, pf_len);
     if (!st && n) {
         DevBuf dc, dt;
-        hipError_t e = dc.alloc(8 * n);
-        if (e == hipSuccess) e = dt.alloc(4 * n);
+        hipError_t e = dc.alloc_once(8 * n);
+        if (e == hipSuccess) e = dt.alloc_once(4 * n);
         if (e == hipSuccess) e = hipMemcpy(dc.p, checker, 8 * n, hipMemcpyHostToDevice);
         if (e == hipSuccess) e = hipMemcpy(dt.p, tf, 4 * n, hipMemcpyHostToDevice);
         if (e != hipSuccess) { set_last_error(std::string("index upload: ") + hipGetErrorString(e)); st = AIX_ERR_HIP; }
@@ -273,7 +301,7 @@ extern "C" int aix_index_create_23(const void* pf_bytes, uint64_t pf_len, const 
 // occ_out (optional, device, ceil(nslots/32) words): bit h set <=> slot h was written by this call.
 static int scatter_device(aix_index* h, uint64_t n, uint64_t nslots, const uint8_t* d_keys, const uint64_t* d_codes, const uint32_t* d_counts,
                           uint64_t* d_checker, uint32_t* d_tf, uint32_t* occ_out, hipStream_t s) {
-    DevBuf occ, flag;
+    DevBuf occ(s), flag(s);
     const uint64_t occ_bytes = 4 * ((nslots + 31) / 32);
     HIPCHK(occ.alloc(occ_bytes));
     HIPCHK(flag.alloc(4));
@@ -351,7 +379,7 @@ extern "C" int aix_index_build_23_codes_dev(const void* pf_bytes, uint64_t pf_le
     DevGuard g(device);
     st = upload_mphf(h, (const uint8_t*)pf_bytes, pf_len);
     if (!st) {
-        DevBuf dc, dt;
+        DevBuf dc((hipStream_t)stream), dt((hipStream_t)stream);
         hipError_t e = dc.alloc(8 * n);
         if (e == hipSuccess) e = dt.alloc(4 * n);
         if (e != hipSuccess) { set_last_error(std::string("index build: ") + hipGetErrorString(e)); st = AIX_ERR_HIP; }
@@ -389,6 +417,20 @@ static int build_13_tables(aix_index* h, const uint64_t* tf_host) {
     const IndexDev d = h->dev();
     HIPCHK(launch_perm13(d.m, h->perm13, 0));
     HIPCHK(launch_tf13_to_code_order(h->perm13, h->tf13_mphf, h->tf13_code, 0));
+    // The streaming counter writes each bin's total to out[perm[code]] with a plain store: right only when code -> slot is a
+    // bijection, which holds for the all-13-mers .pf and not for a foreign one. Checked once here; a handle that fails the check
+    // counts through the atomics path, which adds (the reference's fetch_add at mphf(window), count_kmers13.cpp:147-152).
+    {
+        DevBuf bits, bad;
+        HIPCHK(bits.alloc_once(AIX_TOTAL_13MERS / 8));
+        HIPCHK(bad.alloc_once(4));
+        HIPCHK(hipMemsetAsync(bits.p, 0, AIX_TOTAL_13MERS / 8, 0));
+        HIPCHK(hipMemsetAsync(bad.p, 0, 4, 0));
+        HIPCHK(launch_perm13_check(h->perm13, (uint32_t*)bits.p, (uint32_t*)bad.p, 0));
+        uint32_t nbad = 1;
+        HIPCHK(hipMemcpy(&nbad, bad.p, 4, hipMemcpyDeviceToHost));
+        h->perm13_bijective = (nbad == 0);
+    }
     HIPCHK(hipStreamSynchronize(0));
     return AIX_OK;
 }
@@ -425,6 +467,7 @@ extern "C" int aix_index_open_13(const char* pf, const char* tf_bin, int device,
 extern "C" int aix_index_close(aix_index_t* h) {
     if (!h) return AIX_ERR_ARG;
     destroy(h);
+    pool_trim();                      // scratch blocks cached for this handle's calls go back to the driver with it
     return AIX_OK;
 }
 
@@ -600,7 +643,7 @@ extern "C" int aix_count13_dev(aix_index_t* h, const char* d_plain, uint64_t len
         hipEvent_t ev; hipStream_t st;
         ~RecordOnExit() { (void)hipEventRecord(ev, st); }
     } record_on_exit{h->work13_done, s};
-    const bool use_atomics = getenv("AIX_COUNT13_ATOMICS") != nullptr;             // A/B switch for measurements / tests
+    const bool use_atomics = getenv("AIX_COUNT13_ATOMICS") != nullptr || !h->perm13_bijective;   // env: A/B switch for measurements / tests
     if (use_atomics) {
         if (!h->scratch13) {
             HIPCHK(hipMalloc((void**)&h->scratch13, 8 * AIX_TOTAL_13MERS));
@@ -625,14 +668,21 @@ extern "C" int aix_count13_dev(aix_index_t* h, const char* d_plain, uint64_t len
             h->device_bytes += need;
         }
         HIPCHK(hipMemsetAsync(d_tf_out, 0, 8 * AIX_TOTAL_13MERS, s));
+        HIPCHK(hipMemsetAsync(h->work13, 0, 4, s));                               // the error word of the workspace
         for (uint64_t first = 0; first < nwin; first += piece) {
             const uint64_t w = std::min(piece, nwin - first);
             HIPCHK(launch_count13_partitioned((const uint8_t*)d_plain + first, w + 12, h->work13, nullptr, h->perm13, d_tf_out, first != 0, s));   // fused permutation
         }
+        // a chunk id outside a workgroup's region would have dropped counts: the kernels raise the error word instead of
+        // staying silent, and the call fails (costs one stream wait per call; the table is complete when this returns)
+        uint32_t dropped = 0;
+        HIPCHK(hipMemcpyAsync(&dropped, h->work13, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (dropped) { set_last_error("count13: chunk region exhausted (partition workspace undersized)"); return AIX_ERR_UNSUPPORTED; }
         return AIX_OK;
     }
     HIPCHK(hipMemsetAsync(d_tf_out, 0, 8 * AIX_TOTAL_13MERS, s));
-    HIPCHK(launch_scatter13_to_mphf(h->perm13, h->scratch13, d_tf_out, s));
+    HIPCHK(launch_scatter13_to_mphf(h->perm13, h->scratch13, d_tf_out, h->perm13_bijective ? 0 : 1, s));
     return AIX_OK;
 }
 

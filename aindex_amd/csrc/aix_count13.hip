@@ -11,6 +11,7 @@
 //                         written through the code->mphf permutation — every bin of the output has exactly one writer
 // Nothing is sized before the split, so there is no separate counting pass over the input.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -108,8 +109,11 @@ static constexpr int C13_FILLBITS = 9;                // cursor = (chunk << 9) |
 // Chunk ids need no global allocator: a workgroup that sorts T tiles fills at most T * 128 + 2048 chunks (entries / 256
 // plus one partly filled chunk per partition), so workgroup b owns chunk ids [b * region, (b + 1) * region) and hands them
 // out with the same block scan that orders the tile (the per-partition chunk demand rides in the high half of the scan).
+// A chunk id at or past `region` cannot happen while chunk_region() is right; if it ever does, the write is dropped AND `err`
+// is raised, so the call fails with AIX_ERR_UNSUPPORTED instead of returning short counts.
 __global__ void __launch_bounds__(C13_TB) k_c13_split_chunked(const uint8_t* __restrict__ buf, uint64_t len, uint64_t ntiles, uint32_t region,
-                                                             uint16_t* __restrict__ dir_part, uint16_t* __restrict__ dir_cnt, uint16_t* __restrict__ parts) {
+                                                             uint16_t* __restrict__ dir_part, uint16_t* __restrict__ dir_cnt, uint16_t* __restrict__ parts,
+                                                             uint32_t* __restrict__ err) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t* hist = (uint32_t*)smem;                           // [P + DUMMY] tile-local count per partition; after the scan: first NEW chunk of the partition
     uint32_t* loc_off = hist + C13_P + C13_DUMMY;               // [P] exclusive scan of hist
@@ -162,8 +166,8 @@ __global__ void __launch_bounds__(C13_TB) k_c13_split_chunked(const uint8_t* __r
         loc_off[2 * t + 1] = e0 + a;
         hist[2 * t] = nb0;
         hist[2 * t + 1] = nb1;
-        for (uint32_t i = 0; i < k0; ++i) if (nb0 + i < region) dir_part[region_base + nb0 + i] = (uint16_t)(2 * t);       // fill stays at the pre-set 256
-        for (uint32_t i = 0; i < k1; ++i) if (nb1 + i < region) dir_part[region_base + nb1 + i] = (uint16_t)(2 * t + 1);   // unless it ends up the last one
+        for (uint32_t i = 0; i < k0; ++i) { if (nb0 + i < region) dir_part[region_base + nb0 + i] = (uint16_t)(2 * t); else *err = 1u; }       // fill stays at the pre-set 256
+        for (uint32_t i = 0; i < k1; ++i) { if (nb1 + i < region) dir_part[region_base + nb1 + i] = (uint16_t)(2 * t + 1); else *err = 1u; }   // unless it ends up the last one
         const uint32_t entries = all & 0xFFFFu;
         next_chunk += all >> 16;
         __syncthreads();                                         // loc_off and the chunk bases are complete
@@ -183,7 +187,7 @@ __global__ void __launch_bounds__(C13_TB) k_c13_split_chunked(const uint8_t* __r
             uint32_t chunk, o;
             if (pos < (uint32_t)C13_CH) { chunk = c >> C13_FILLBITS; o = pos; }
             else { chunk = hist[p] + (pos - C13_CH) / C13_CH; o = (pos - C13_CH) % C13_CH; }
-            if (chunk < region) parts[(uint64_t)(region_base + chunk) * C13_CH + o] = (uint16_t)e;
+            if (chunk < region) parts[(uint64_t)(region_base + chunk) * C13_CH + o] = (uint16_t)e; else *err = 1u;
         }
         __syncthreads();
 #pragma unroll
@@ -204,7 +208,7 @@ __global__ void __launch_bounds__(C13_TB) k_c13_split_chunked(const uint8_t* __r
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const uint32_t c = cursor[2 * t + q], fill = c & FILLMASK, chunk = c >> C13_FILLBITS;
-        if (fill < (uint32_t)C13_CH && chunk < region) dir_cnt[region_base + chunk] = (uint16_t)fill;
+        if (fill < (uint32_t)C13_CH) { if (chunk < region) dir_cnt[region_base + chunk] = (uint16_t)fill; else *err = 1u; }
     }
 }
 
@@ -277,6 +281,7 @@ static constexpr unsigned C13_MAXGRID = 512;
 static inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
 // chunk ids one workgroup can need: 128 per tile it sorts + one partly filled chunk per partition
 static inline uint32_t chunk_region(uint64_t nwin) {
+    if (const char* e = getenv("AIX_COUNT13_TEST_REGION")) { const long v = atol(e); if (v > 0) return (uint32_t)v; }   // test hook: an undersized region must fail loudly
     const uint64_t ntiles = (nwin + C13_TILE - 1) / C13_TILE;
     const uint64_t grid = std::min<uint64_t>(ntiles ? ntiles : 1, C13_MAXGRID);
     return (uint32_t)((ntiles + grid - 1) / grid * (C13_TILE / C13_CH) + C13_P);
@@ -292,7 +297,7 @@ static size_t dir_sort_temp_bytes(uint32_t cap) {
     return bytes;
 }
 
-// workspace (chunked path): (256 B unused) | dir_part u16[cap] | dir_cnt u16[cap] | spart u16[cap] | sdesc u64[cap] | sort temp | parts u16[cap * 256]
+// workspace (chunked path): error word (first 4 of 256 B) | dir_part u16[cap] | dir_cnt u16[cap] | spart u16[cap] | sdesc u64[cap] | sort temp | parts u16[cap * 256]
 // `len` = bytes handed to one launch (<= 2^31 + 12)
 uint64_t count13_workspace_bytes(uint64_t len) {
     const uint64_t nwin = len >= 13 ? len - 12 : 0;
@@ -306,6 +311,7 @@ hipError_t launch_count13_partitioned(const uint8_t* buf, uint64_t len, void* wo
     if (nwin > (1ull << 31)) return hipErrorInvalidValue;
     const uint32_t cap = chunk_capacity(nwin);
     uint8_t* w = (uint8_t*)workspace;
+    uint32_t* err = (uint32_t*)w;                             // sticky inside one call: the caller zeroes it before the first piece and reads it after the last
     w += 256;
     uint16_t* dir_part = (uint16_t*)w;                        w += align_up(2ull * cap, 256);
     uint16_t* dir_cnt = (uint16_t*)w;                         w += align_up(2ull * cap, 256);
@@ -327,7 +333,7 @@ hipError_t launch_count13_partitioned(const uint8_t* buf, uint64_t len, void* wo
     hipError_t e = hipMemsetD16Async((hipDeviceptr_t)dir_part, (unsigned short)C13_P, cap, s);     // "no partition": sorts behind every real one
     if (e == hipSuccess) e = hipMemsetD16Async((hipDeviceptr_t)dir_cnt, (unsigned short)C13_CH, cap, s);     // chunks are full unless the split says otherwise
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_c13_split_chunked, dim3(grid), dim3(C13_TB), split_lds, s, buf, len, ntiles, chunk_region(nwin), dir_part, dir_cnt, parts);
+    hipLaunchKernelGGL(k_c13_split_chunked, dim3(grid), dim3(C13_TB), split_lds, s, buf, len, ntiles, chunk_region(nwin), dir_part, dir_cnt, parts, err);
     auto vals = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), ChunkDesc{dir_cnt});
     e = rocprim::radix_sort_pairs(tmp, tmp_bytes, (const uint16_t*)dir_part, spart, vals, sdesc, (size_t)cap, 0u, 12u, s);
     if (e != hipSuccess) return e;

@@ -58,7 +58,8 @@ uint64_t count13_workspace_bytes(uint64_t len);
 // perm/out_mphf set: counters are written straight into the (pre-zeroed) mphf-ordered output; else into table_code
 hipError_t launch_count13_partitioned(const uint8_t* buf, uint64_t len, void* workspace, unsigned long long* table_code, const uint32_t* perm,
                                       uint64_t* out_mphf, int accumulate, hipStream_t s);
-hipError_t launch_scatter13_to_mphf(const uint32_t* perm, const unsigned long long* table_code, uint64_t* out_mphf, hipStream_t s);
+hipError_t launch_scatter13_to_mphf(const uint32_t* perm, const unsigned long long* table_code, uint64_t* out_mphf, int add, hipStream_t s);
+hipError_t launch_perm13_check(const uint32_t* perm, uint32_t* bits /* 4^13 / 32 zeroed words */, uint32_t* bad /* zeroed */, hipStream_t s);
 hipError_t launch_count23_fixed(const IndexDev& ix, const uint8_t* buf, uint64_t len, int canon_mode, uint32_t* tf_out, hipStream_t s);
 
 hipError_t launch_window_codes(const uint8_t* buf, uint64_t len, int k, int canon_mode, uint64_t* out /* [len-k+1] */, hipStream_t s);

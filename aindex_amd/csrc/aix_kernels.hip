@@ -445,12 +445,29 @@ __global__ void __launch_bounds__(kBlock) k_tf13_to_code(const uint32_t* __restr
         tf_code[code] = h < 67108864u ? tf_mphf[h] : 0ull;
     }
 }
+// ADD: the MPHF is not a bijection on the 13-mers (a foreign .pf): several codes may share a slot, and the reference's
+// counts[mphf(window)].fetch_add(1) (count_kmers13.cpp:147-152) then sums them; slots >= 4^13 are skipped as there.
+template <bool ADD>
 __global__ void __launch_bounds__(kBlock) k_scatter13(const uint32_t* __restrict__ perm, const unsigned long long* __restrict__ table_code, uint64_t* __restrict__ out_mphf) {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t code = (uint64_t)blockIdx.x * kBlock + threadIdx.x; code < 67108864ull; code += stride) {
         const uint32_t h = perm[code];
-        if (h < 67108864u) out_mphf[h] = table_code[code];
+        if (h >= 67108864u) continue;
+        if (ADD) { const unsigned long long c = table_code[code]; if (c) atomicAdd((unsigned long long*)&out_mphf[h], c); }
+        else out_mphf[h] = table_code[code];
     }
+}
+// is code -> slot a bijection of [0, 4^13)? every slot in range and claimed once (bits: 4^13 / 32 zeroed words)
+__global__ void __launch_bounds__(kBlock) k_perm13_check(const uint32_t* __restrict__ perm, uint32_t* __restrict__ bits, uint32_t* __restrict__ bad) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    uint32_t b = 0;
+    for (uint64_t code = (uint64_t)blockIdx.x * kBlock + threadIdx.x; code < 67108864ull; code += stride) {
+        const uint32_t h = perm[code];
+        if (h >= 67108864u) { b = 1; continue; }
+        const uint32_t bit = 1u << (h & 31);
+        if (atomicOr(&bits[h >> 5], bit) & bit) b = 1;
+    }
+    if (__any(b) && (threadIdx.x & 63) == 0) atomicAdd(bad, 1u);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -726,8 +743,12 @@ hipError_t launch_count13_plain(const uint8_t* buf, uint64_t len, unsigned long 
     if (len < 13) return hipSuccess;
     AIX_LAUNCH(k_count13, len - 12, s, buf, len, table);
 }
-hipError_t launch_scatter13_to_mphf(const uint32_t* perm, const unsigned long long* table, uint64_t* out, hipStream_t s) {
-    AIX_LAUNCH(k_scatter13, 67108864ull, s, perm, table, out);
+hipError_t launch_scatter13_to_mphf(const uint32_t* perm, const unsigned long long* table, uint64_t* out, int add, hipStream_t s) {
+    if (add) AIX_LAUNCH(k_scatter13<true>, 67108864ull, s, perm, table, out);
+    AIX_LAUNCH(k_scatter13<false>, 67108864ull, s, perm, table, out);
+}
+hipError_t launch_perm13_check(const uint32_t* perm, uint32_t* bits, uint32_t* bad, hipStream_t s) {
+    AIX_LAUNCH(k_perm13_check, 67108864ull, s, perm, bits, bad);
 }
 hipError_t launch_count23_fixed(const IndexDev& ix, const uint8_t* buf, uint64_t len, int canon_mode, uint32_t* tf_out, hipStream_t s) {
     if (len < 23 || ix.n == 0) return hipSuccess;

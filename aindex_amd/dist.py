@@ -109,6 +109,41 @@ def count23_sharded(index, plain: bytes, canon_mode: int = 2, device=None):
     return all_reduce_sum_(out)
 
 
+def count13_sharded_t(index, plain_t, out_t=None):
+    """Device-tensor twin of count13_sharded: `plain_t` is THIS rank's record-aligned share of the reads, already in HBM
+    (uint8 tensor on the index's device) — nothing is uploaded from host memory. Counts it and all-reduces the 4^13 table
+    in place (RCCL under "nccl"). Returns the int64 tensor [4^13] (mphf order) with the global counts on every rank."""
+    out_t = index.count13_t(plain_t, out_t)
+    return all_reduce_sum_(out_t)
+
+
+def count23_sharded_t(index, plain_t, canon_mode: int = 2, out_t=None):
+    """Device-tensor twin of count23_sharded: this rank's share of the reads is already in HBM; histogram against the
+    fixed key set into `out_t` (int32 [n], zeroed here) and ONE all-reduce(sum) — the only collective of the counting path
+    (BASELINE configs[3]). Returns the global histogram on every rank."""
+    import torch
+    if out_t is None:
+        out_t = torch.zeros(index.n, dtype=torch.int32, device=plain_t.device)
+    else:
+        out_t.zero_()
+    index.count23_fixed_t(plain_t, canon_mode, out_t)
+    return all_reduce_sum_(out_t)
+
+
+def _raise_together(local_error, what: str, device="cpu"):
+    """Collective error handling: a rank that failed locally must not leave the others blocked inside the next collective.
+    Every rank contributes a 0/1 flag to ONE all-reduce and all of them raise (or none does)."""
+    import torch
+    import torch.distributed as dist
+    flag = torch.tensor([1 if local_error is not None else 0], dtype=torch.int32, device=device)
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("AIX_FORCE_DIST")):
+        dist.all_reduce(flag, op=dist.ReduceOp.SUM)
+    if int(flag.item()):
+        if local_error is not None:
+            raise RuntimeError(f"{what}: {local_error}") from (local_error if isinstance(local_error, BaseException) else None)
+        raise RuntimeError(f"{what}: failed on another rank")
+
+
 def lookup_sharded(index, kmers_u8, device=None):
     """Batch tf lookup with the queries split into contiguous ranges over the ranks (index replicated); every rank
     returns only ITS range [lo, hi) as (lo, hi, uint32 numpy array) — no collective on the data path."""
@@ -231,11 +266,16 @@ def scatter_sharded(pf_bytes: bytes, keys_u8, counts=None, device: int = 0):
     pf = np.frombuffer(pf_bytes, dtype=np.uint8)
     st = lib().aix_index_scatter_shard(pf.ctypes.data_as(vp), pf.shape[0], mine.ctypes.data_as(vp), cnt.ctypes.data_as(vp) if cnt is not None else None,
                                        hi - lo, n, device, checker.ctypes.data_as(vp), tf.ctypes.data_as(vp), occ.ctypes.data_as(vp))
-    if st != AIX_ERR_CONFLICT:
-        check(st, "aix_index_scatter_shard")
     import torch.distributed as dist
     on_gpu = dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
     dev = f"cuda:{device}" if on_gpu else "cpu"
+    err = None
+    if st not in (0, AIX_ERR_CONFLICT):             # OOM, HIP error, malformed .pf ...: every rank raises, none is left in a collective
+        try:
+            check(st, "aix_index_scatter_shard")
+        except Exception as e:
+            err = e
+    _raise_together(err, "scatter_sharded", dev)
     occ_bits = np.unpackbits(occ.view(np.uint8), bitorder="little")[:n].astype(np.int32)
     ct = torch.from_numpy(checker.view(np.int64)).to(dev)
     tt = torch.from_numpy(tf.view(np.int32)).to(dev)
@@ -279,7 +319,13 @@ def positions_fill_sharded(index, reads: bytes):
     else:
         exs = [ex]
     first = all(int(e.item()) == 1 for e in exs[:rank])
-    counts = torch.from_numpy(index.positions_bucket_counts(mine, first).view(np.int64)).to(dev)
+    err, counts_np = None, None
+    try:
+        counts_np = index.positions_bucket_counts(mine, first)
+    except Exception as e:                                # a failing rank must not leave the others inside the all-gather
+        err = e
+    _raise_together(err, "positions_fill_sharded (tally)", dev)
+    counts = torch.from_numpy(counts_np.view(np.int64)).to(dev)
     if active and world > 1:
         allc = [torch.empty_like(counts) for _ in range(world)]
         dist.all_gather(allc, counts)
@@ -289,9 +335,13 @@ def positions_fill_sharded(index, reads: bytes):
     for r in range(rank):
         before += allc[r]
     filled = torch.clamp(before, max=(1 << 32) - 1).cpu().numpy().astype(np.uint32)
-    indices = index.positions_indices()
-    total = int(indices[-1])
-    part = index.positions_fill_shard(mine, total, first, lo, filled)
+    indices, part = None, None
+    try:
+        indices = index.positions_indices()
+        part = index.positions_fill_shard(mine, int(indices[-1]), first, lo, filled)
+    except Exception as e:
+        err = e
+    _raise_together(err, "positions_fill_sharded (fill)", dev)
     pt = torch.from_numpy(part.view(np.int64)).to(dev)
     all_reduce_sum_(pt)                                   # every entry is written by exactly one rank
     return indices, pt.cpu().numpy().view(np.uint64)

@@ -39,9 +39,11 @@ def _ragged(items: Sequence) -> Tuple[np.ndarray, np.ndarray]:
     return np.frombuffer(b"".join(bs), dtype=np.uint8), offs
 
 
-def _stream_ptr():
+def _stream_ptr(device=None):
+    """torch's current stream ON `device` (the index's device): the library switches to the handle's device for the call,
+    so a stream of whichever device happens to be current would be a stream of the wrong device."""
     import torch
-    return vp(torch.cuda.current_stream().cuda_stream)
+    return vp(torch.cuda.current_stream(device).cuda_stream)
 
 
 class Index:
@@ -97,7 +99,7 @@ class Index:
         with torch.cuda.device(dev):
             check(lib().aix_index_build_23_codes_dev(_np_ptr(buf), buf.shape[0], vp(keys_t.data_ptr()),
                                                      vp(counts_t.data_ptr()) if counts_t is not None else None,
-                                                     keys_t.numel(), dev, _stream_ptr(), C.byref(h)), "aix_index_build_23_codes_dev")
+                                                     keys_t.numel(), dev, _stream_ptr(dev), C.byref(h)), "aix_index_build_23_codes_dev")
         return cls(h)
 
     def close(self):
@@ -287,7 +289,7 @@ class Index:
         n = kmers_t.numel() // self.k
         if out_t is None:
             out_t = torch.empty(n, dtype=torch.int32, device=kmers_t.device)   # u32 bit patterns
-        check(lib().aix_tf_batch_ascii_dev(self._h, vp(kmers_t.data_ptr()), n, vp(out_t.data_ptr()), _stream_ptr()),
+        check(lib().aix_tf_batch_ascii_dev(self._h, vp(kmers_t.data_ptr()), n, vp(out_t.data_ptr()), _stream_ptr(self.device)),
               "aix_tf_batch_ascii_dev")
         return out_t
 
@@ -297,7 +299,7 @@ class Index:
         self._chk_dev(kmers_t)
         n = kmers_t.numel() // self.k
         out_t = torch.empty(n, dtype=torch.int32, device=kmers_t.device)
-        check(lib().aix_lines_batch_ascii_dev(self._h, vp(kmers_t.data_ptr()), n, vp(out_t.data_ptr()), _stream_ptr()), "aix_lines_batch_ascii_dev")
+        check(lib().aix_lines_batch_ascii_dev(self._h, vp(kmers_t.data_ptr()), n, vp(out_t.data_ptr()), _stream_ptr(self.device)), "aix_lines_batch_ascii_dev")
         return out_t
 
     def tf_codes_t(self, codes_t, out_t=None):
@@ -306,7 +308,7 @@ class Index:
         n = codes_t.numel()
         if out_t is None:
             out_t = torch.empty(n, dtype=torch.int32, device=codes_t.device)
-        check(lib().aix_tf_batch_codes_dev(self._h, vp(codes_t.data_ptr()), n, vp(out_t.data_ptr()), _stream_ptr()),
+        check(lib().aix_tf_batch_codes_dev(self._h, vp(codes_t.data_ptr()), n, vp(out_t.data_ptr()), _stream_ptr(self.device)),
               "aix_tf_batch_codes_dev")
         return out_t
 
@@ -316,7 +318,7 @@ class Index:
         n = kmers_t.numel() // self.k
         if out_t is None:
             out_t = torch.empty(n, dtype=torch.int64, device=kmers_t.device)
-        check(lib().aix_tf_total_batch_ascii_dev(self._h, vp(kmers_t.data_ptr()), n, vp(out_t.data_ptr()), _stream_ptr()),
+        check(lib().aix_tf_total_batch_ascii_dev(self._h, vp(kmers_t.data_ptr()), n, vp(out_t.data_ptr()), _stream_ptr(self.device)),
               "aix_tf_total_batch_ascii_dev")
         return out_t
 
@@ -327,7 +329,7 @@ class Index:
         if out_t is None:
             out_t = torch.zeros(total_out, dtype=torch.int32, device=seqs_t.device)
         check(lib().aix_coverage_batch_dev(self._h, vp(seqs_t.data_ptr()), vp(offs_t.data_ptr()), m, seqs_t.numel(), cutoff,
-                                           vp(out_t.data_ptr()), vp(out_offs_t.data_ptr()), _stream_ptr()), "aix_coverage_batch_dev")
+                                           vp(out_t.data_ptr()), vp(out_offs_t.data_ptr()), _stream_ptr(self.device)), "aix_coverage_batch_dev")
         return out_t
 
     def positions_fill_t(self, reads_t):
@@ -350,7 +352,7 @@ class Index:
         pos = torch.empty(max(total.value, 1), dtype=torch.int64, device=dev)[: total.value]
         with torch.cuda.device(dev):
             check(lib().aix_positions_fill_dev(self._h, vp(reads_t.data_ptr()), reads_t.numel(), start.value, vp(indices.data_ptr()),
-                                               vp(pos.data_ptr()) if total.value else None, total.value, _stream_ptr()), "aix_positions_fill_dev")
+                                               vp(pos.data_ptr()) if total.value else None, total.value, _stream_ptr(self.device)), "aix_positions_fill_dev")
         return indices, pos
 
     def count13_t(self, plain_t, out_t=None):
@@ -358,7 +360,7 @@ class Index:
         self._chk_dev(plain_t)
         if out_t is None:
             out_t = torch.empty(_lib.TOTAL_13MERS, dtype=torch.int64, device=plain_t.device)
-        check(lib().aix_count13_dev(self._h, vp(plain_t.data_ptr()), plain_t.numel(), vp(out_t.data_ptr()), _stream_ptr()),
+        check(lib().aix_count13_dev(self._h, vp(plain_t.data_ptr()), plain_t.numel(), vp(out_t.data_ptr()), _stream_ptr(self.device)),
               "aix_count13_dev")
         return out_t
 
@@ -369,7 +371,7 @@ class Index:
         if out_t is None:
             out_t = torch.zeros(self.n, dtype=torch.int32, device=plain_t.device)
         check(lib().aix_count23_fixed_dev(self._h, vp(plain_t.data_ptr()), plain_t.numel(), canon_mode, vp(out_t.data_ptr()),
-                                          _stream_ptr()), "aix_count23_fixed_dev")
+                                          _stream_ptr(self.device)), "aix_count23_fixed_dev")
         return out_t
 
 

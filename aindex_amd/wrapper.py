@@ -126,7 +126,16 @@ class AindexWrapper:
         self.reads_size = int(self._reads.shape[0])
         self.load_reads_index(reads_file[: reads_file.rfind(".")] + ".ridx")
 
-    load_reads_in_memory = load_reads                                                   # :324-359
+    def load_reads_in_memory(self, reads_file: str):
+        """:324-359 — the same as load_reads, but the bytes are read into a private buffer (`new char[length]` there)
+        instead of being mapped: later changes to the file do not show through. An unreadable file leaves the wrapper
+        without reads, as the reference's early `return` does (:337-340)."""
+        if not os.path.isfile(reads_file):
+            self._reads, self.reads_size = None, 0
+            return
+        self._reads = np.fromfile(reads_file, dtype=np.uint8)
+        self.reads_size = int(self._reads.shape[0])
+        self.load_reads_index(reads_file[: reads_file.rfind(".")] + ".ridx")
 
     def load_aindex(self, index_file: str, indices_file: str, max_tf: int = 0):
         """:361-402 — .index.bin (positions, 1-based, 0 = empty) and .indices.bin (n+1 offsets)."""

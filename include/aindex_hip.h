@@ -64,8 +64,8 @@ const char* aix_version(void);
 const char* aix_strerror(int status);
 int aix_device_count(int* count);
 /* Calls that need multi-GB temporaries (K1, A1/A2, I1, host-buffer staging) take them from a per-device cache of device
- * blocks (a hipMalloc of that size costs ~20 ms). AIX_SCRATCH_CACHE_GB (default 64) bounds the cache; this returns it
- * to the driver. */
+ * blocks (a hipMalloc of that size costs ~20 ms). AIX_SCRATCH_CACHE_GB (default 16) bounds the cache; this and
+ * aix_index_close() return it to the driver. */
 void aix_scratch_trim(void);                     /* AIX_ERR_HIP if the runtime is unusable  */
 
 /* ------------------------------------------------------------------------------------------
@@ -76,6 +76,12 @@ void aix_scratch_trim(void);                     /* AIX_ERR_HIP if the runtime i
  * File layouts are the reference's: .pf = mphf::save (mphf.hpp:99-105), .kmers.bin = u64[n],
  * .tf.bin = u32[n] (23-mer, compute_index.cpp:59-67) or u64[4^13] (13-mer, count_kmers13.cpp:358-388).
  * ------------------------------------------------------------------------------------------ */
+/* Validate a .pf image on the HOST (no device needed): header u64 n, hash_domain, seed, bitpairs (mphf.hpp:99-113,
+ * base_hash.hpp:116-119, ranked_bitpair_vector.hpp:78-84), bitpairs == 3 * hash_domain without wrap-around, node ids
+ * within 32 bits, n <= bitpairs, and the image long enough for the bit-pair words and block ranks. Every open / create /
+ * scatter entry point applies the same check before anything is uploaded: AIX_ERR_FORMAT instead of an out-of-bounds
+ * read on the device (the reference trusts the header). hdr_out (nullable) receives the four header words. */
+int aix_pf_check(const void* pf_bytes, uint64_t pf_len, uint64_t hdr_out[4]);
 int aix_index_open_23(const char* pf_path, const char* tf_bin_path, const char* kmers_bin_path,
                       int device, aix_index_t** out);
 int aix_index_open_13(const char* pf_path, const char* tf_bin_path /* NULL: all-zero table */,

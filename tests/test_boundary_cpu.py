@@ -1,0 +1,111 @@
+"""Boundary checks that need no GPU: the executable shims under bin/ (the names aindex/cli.py:run_executable spawns,
+cli.py:214-278), the .pf header validation of the ABI, and the host-side reads loaders of the AindexWrapper mirror."""
+import ctypes as C
+import json
+import os
+import struct
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from aindex_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "bin")
+SHIMS = ("count_kmers13", "kmer_counter", "compute_mphf_seq", "compute_index", "compute_aindex", "compute_reads")
+
+
+def _run(name, *args, cwd=None):
+    return subprocess.run([os.path.join(BIN, name), *args], stdout=subprocess.PIPE, stderr=subprocess.PIPE, cwd=cwd, timeout=300)
+
+
+@pytest.mark.parametrize("name", SHIMS)
+def test_shim_is_an_executable_with_the_reference_name_and_usage_status(name):
+    """cli.py:243-262 looks for <bin>/<name> and runs it; without arguments every reference tool prints its usage and exits
+    non-zero (count_kmers13.cpp:546-551, count_kmers.cpp:394-399, compute_mphf_generic.hpp:21-26, compute_index.cpp:36-41,
+    compute_aindex.cpp:30-35, compute_reads.cpp:24-29)."""
+    path = os.path.join(BIN, name)
+    assert os.path.isfile(path) and os.access(path, os.X_OK)
+    r = _run(name)
+    assert r.returncode == 1, r.stderr
+    assert name in r.stderr.decode() or "Expected" in r.stderr.decode()
+
+
+def test_compute_reads_shim_reproduces_the_reference_files(gold, tmp_path):
+    d = os.path.join(gold, "compute_reads")
+    prefix = str(tmp_path / "se")
+    r = _run("compute_reads", os.path.join(d, "in_test_se.fastq"), "-", "se", prefix)
+    assert r.returncode == 0, r.stderr
+    for ext in (".reads", ".ridx"):
+        assert open(prefix + ext, "rb").read() == open(os.path.join(d, "se" + ext), "rb").read()
+    assert _run("compute_reads", os.path.join(d, "in_test_se.fastq"), "-", "nonsense", prefix).returncode == 2     # compute_reads.cpp:214
+
+
+def test_compute_mphf_seq_shim_writes_the_reference_pf(gold, small23_prefix, tmp_path):
+    """`compute_mphf_seq <keys> <out.pf>` through the shim (host MWHC builder, no GPU): byte-identical to the .pf the
+    compiled reference wrote for the same keys (tests/golden/small23/small23.pf)."""
+    keys = str(tmp_path / "keys.txt")
+    with open(keys, "w") as f:
+        for ln in open(small23_prefix + ".dat"):
+            f.write(ln.split("\t")[0] + "\n")
+    out = str(tmp_path / "out.pf")
+    r = _run("compute_mphf_seq", keys, out)
+    assert r.returncode == 0, r.stderr
+    assert open(out, "rb").read() == open(small23_prefix + ".pf", "rb").read()
+
+
+def _pf_check(buf: bytes):
+    hdr = (C.c_uint64 * 4)()
+    a = np.frombuffer(buf, dtype=np.uint8) if buf else np.zeros(1, np.uint8)
+    return _lib.lib().aix_pf_check(a.ctypes.data_as(C.c_void_p), len(buf), C.byref(hdr)), list(hdr)
+
+
+def test_pf_header_validation(small23_prefix):
+    """A corrupt header must be refused on the host, before any upload (D = 0x5555555555555556, B = 2 passes a
+    wrapping `B == 3 * D` and would index the record table at ~2^62 on the device)."""
+    good = open(small23_prefix + ".pf", "rb").read()
+    st, hdr = _pf_check(good)
+    n, D, seed, B = struct.unpack("<4Q", good[:32])
+    assert st == 0 and hdr == [n, D, seed, B] and B == 3 * D
+    fmt = -3
+    assert _pf_check(good[:31])[0] == fmt                                            # shorter than the header
+    assert _pf_check(good[:-8])[0] == fmt                                            # block ranks cut short
+    wrap = struct.pack("<4Q", 1, 0x5555555555555556, seed, 2) + good[32:]
+    assert (3 * 0x5555555555555556) % (1 << 64) == 2 and _pf_check(wrap)[0] == fmt   # 3 * D wraps around to B
+    assert _pf_check(struct.pack("<4Q", n, D, seed, B + 1) + good[32:])[0] == fmt    # B != 3 D
+    assert _pf_check(struct.pack("<4Q", B + 1, D, seed, B) + good[32:])[0] == fmt    # more keys than bit-pairs
+    big_d = (1 << 32) // 3 + 1
+    assert _pf_check(struct.pack("<4Q", 1, big_d, seed, 3 * big_d) + good[32:])[0] == fmt   # node ids beyond 32 bits
+    assert _pf_check(struct.pack("<4Q", 0, 0, seed, 0))[0] == 0                      # the MPHF of an empty key set (mphf.hpp:26)
+    assert _lib.lib().aix_pf_check(None, 64, None) == -1
+
+
+def test_load_reads_in_memory_and_mapped_agree_with_the_reference_answers(gold, small23_prefix, tmp_path):
+    """load_reads (python_wrapper.cpp:281-322, mmap) and load_reads_in_memory (:324-359, private copy) give the same reads
+    access; answers = those of the compiled reference (tests/golden/small23/access.json). Host-side only."""
+    from aindex_amd.wrapper import AindexWrapper
+    a = json.load(open(os.path.join(gold, "small23", "access.json")))
+    reads = str(tmp_path / "copy.reads")
+    with open(reads, "wb") as f:
+        f.write(open(small23_prefix + ".reads", "rb").read())
+    with open(str(tmp_path / "copy.ridx"), "wb") as f:
+        f.write(open(small23_prefix + ".ridx", "rb").read())
+    for loader in ("load_reads", "load_reads_in_memory"):
+        w = AindexWrapper()
+        getattr(w, loader)(reads)
+        assert w.n_reads == a["n_reads"] and w.reads_size == a["reads_size"] and w.get_reads_size() == a["reads_size"]
+        for rid, read in a["read_by_rid"].items():
+            assert w.get_read_by_rid(int(rid)) == read
+        for s0, e0, rcflag, want in a["get_read"]:
+            assert w.get_read(s0, e0, rcflag) == want
+    # the in-memory copy is private: truncating the file afterwards does not show through (:349-351 reads it all up front)
+    w = AindexWrapper()
+    w.load_reads_in_memory(reads)
+    first = w.get_read_by_rid(0)
+    open(reads, "wb").close()
+    assert w.get_read_by_rid(0) == first == a["read_by_rid"]["0"]
+    w2 = AindexWrapper()
+    w2.load_reads_in_memory(str(tmp_path / "missing.reads"))                          # :337-340: message, early return
+    assert w2.reads_size == 0 and w2.get_read_by_rid(0) == ""
