@@ -67,6 +67,11 @@ struct aix_index {
     BvRec* recs = nullptr;
     EeRec* ee = nullptr;                       // early-exit table (23-mer handles with keys)
     KeyRec* keys = nullptr;
+    BkEntry* bk = nullptr;                     // verification table: nb buckets of eight {code, tf, slot} entries (one 128-byte line each)
+    uint32_t nb = 0;
+    uint32_t bk_lpp = 8;                       // lanes that share one bucket read
+    uint64_t bk_unfiled = 0;                   // keys beyond the eighth of their bucket (answered through the MPHF)
+    bool bk_enabled = true;
     uint64_t* tf13_mphf = nullptr;
     uint64_t* tf13_code = nullptr;
     uint32_t* perm13 = nullptr;
@@ -106,6 +111,9 @@ struct aix_index {
         d.k = k;
         d.use_fp = (has_fp && fp_filter) ? 1u : 0u;
         d.early_exit = (has_fp && ee && early_exit) ? 1u : 0u;
+        d.bk = (bk && bk_enabled) ? bk : nullptr;
+        d.nb = nb;
+        d.bk_lpp = bk_lpp;
         return d;
     }
 };
@@ -233,6 +241,7 @@ static void destroy(aix_index* h) {
     if (h->recs) (void)hipFree(h->recs);
     if (h->ee) (void)hipFree(h->ee);
     if (h->keys) (void)hipFree(h->keys);
+    if (h->bk) (void)hipFree(h->bk);
     if (h->tf13_mphf) (void)hipFree(h->tf13_mphf);
     if (h->tf13_code) (void)hipFree(h->tf13_code);
     if (h->perm13) (void)hipFree(h->perm13);
@@ -244,6 +253,36 @@ static void destroy(aix_index* h) {
     if (h->pin_cov) (void)hipHostFree(h->pin_cov);
     for (void* p : h->pin_out) if (p) (void)hipHostFree(p);
     delete h;
+}
+
+// Verification table: n / load buckets of one 128-byte line. AIX_BUCKET_LOAD = mean keys per 8-entry bucket
+// (default 4: 32 B of HBM per key, 2 % of the buckets overflow and 0.4 % of the keys stay with the MPHF path);
+// AIX_BUCKET_TABLE=0 skips it (every probe through the MPHF records + key records, as in round 1).
+static int build_bucket_table(aix_index* h, hipStream_t s) {
+    if (h->n == 0) return AIX_OK;
+    if (const char* e = getenv("AIX_BUCKET_TABLE")) { if (atoi(e) == 0) return AIX_OK; }
+    double load = 4.0;
+    if (const char* e = getenv("AIX_BUCKET_LOAD")) { const double v = atof(e); if (v >= 0.25 && v <= 8.0) load = v; }
+    if (const char* e = getenv("AIX_BUCKET_LANES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) h->bk_lpp = (uint32_t)v; }
+    uint64_t nb = (uint64_t)((double)h->n / load) + 1;
+    if (nb > 0xFFFFFFF0ull) nb = 0xFFFFFFF0ull;
+    const uint64_t bytes = nb * 8 * sizeof(BkEntry);
+    DevBuf fill(s);
+    HIPCHK(fill.alloc_once(4 * nb));
+    HIPCHK(hipMalloc((void**)&h->bk, bytes));
+    h->nb = (uint32_t)nb;
+    h->device_bytes += bytes;
+    HIPCHK(hipMemsetAsync(fill.p, 0, 4 * nb, s));
+    HIPCHK(launch_build_buckets(h->dev().m, h->keys, h->n, h->bk, h->nb, (uint32_t*)fill.p, s));
+    // keys left to the MPHF path: sum over buckets of max(fill - 8, 0) (host side: once per open, nb words)
+    std::vector<uint32_t> f;
+    try { f.resize(nb); } catch (const std::bad_alloc&) { return AIX_ERR_NOMEM; }
+    HIPCHK(hipMemcpyAsync(f.data(), fill.p, 4 * nb, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    uint64_t unfiled = 0;
+    for (uint64_t i = 0; i < nb; ++i) if (f[i] > 8) unfiled += f[i] - 8;
+    h->bk_unfiled = unfiled;
+    return AIX_OK;
 }
 
 // interleave device-resident checker[]/tf[] into KeyRec records and detect an all-canonical key set
@@ -267,7 +306,7 @@ static int adopt_device_arrays(aix_index* h, const uint64_t* d_checker, const ui
     HIPCHK(launch_set_fingerprints(h->dev().m, h->recs, h->ee, h->keys, n, s));
     HIPCHK(hipStreamSynchronize(s));
     h->has_fp = true;
-    return AIX_OK;
+    return build_bucket_table(h, s);
 }
 
 extern "C" int aix_index_create_23(const void* pf_bytes, uint64_t pf_len, const uint64_t* checker, const uint32_t* tf, uint64_t n, int device,
@@ -477,6 +516,10 @@ extern "C" int aix_index_info(const aix_index_t* h, aix_info_t* info) {
     info->k = h->k; info->device = (uint32_t)h->device; info->n = h->n; info->mphf_n = h->mphf_n;
     info->hash_domain = h->D; info->seed = h->seed; info->bitpairs = h->B; info->device_bytes = h->device_bytes;
     info->canonical_only = h->canonical_only ? 1 : 0;
+    info->bucket_table = (h->bk && h->bk_enabled) ? 1 : 0;
+    info->bucket_lanes = h->bk_lpp;
+    info->buckets = h->bk ? h->nb : 0;
+    info->bucket_unfiled_keys = h->bk_unfiled;
     return AIX_OK;
 }
 
@@ -495,6 +538,14 @@ extern "C" int aix_index_set_fingerprint_filter(aix_index_t* h, int enabled) {
 extern "C" int aix_index_set_early_exit(aix_index_t* h, int enabled) {
     if (!h) return AIX_ERR_ARG;
     h->early_exit = enabled != 0;
+    return AIX_OK;
+}
+
+extern "C" int aix_index_set_bucket_table(aix_index_t* h, int enabled, int lanes) {
+    if (!h) return AIX_ERR_ARG;
+    if (lanes != 0 && lanes != 1 && lanes != 2 && lanes != 4 && lanes != 8) return AIX_ERR_ARG;
+    h->bk_enabled = enabled != 0;
+    if (lanes) h->bk_lpp = (uint32_t)lanes;
     return AIX_OK;
 }
 

@@ -47,6 +47,24 @@ struct __attribute__((aligned(16))) KeyRec {
     uint32_t pad;
 };
 
+// Verification table of a 23-mer index ("bucket table"): ONE 128-byte line per probe instead of three MPHF records plus a
+// key record. Every stored key that sits in its own MPHF slot (the only way the reference can find it: `checker[mphf(q)] ==
+// code(q)`, python_wrapper.cpp:610-627) is filed under a bucket chosen by its Jenkins hash; a bucket is eight 16-byte
+// entries {code, tf, slot}. A probe whose hashed bytes are the ASCII of its code reads its bucket and compares the codes
+// in the line: a match is the reference's hit (slot = the MPHF value, tf = tf[slot]); no match in a bucket that never
+// overflowed is the reference's miss. Keys beyond the eighth of a bucket are not filed: the bucket's last entry carries an
+// overflow bit and an unmatched probe of such a bucket takes the MPHF path (exact either way).
+struct __attribute__((aligned(16))) BkEntry {
+    uint32_t code_lo;
+    uint32_t code_hi;    // bits 0..13: code bits 32..45; bits 14..29 zero for a key, all ones for an empty entry; bit 31 (entry 7 only): overflow
+    uint32_t tf;
+    uint32_t slot;
+};
+#define AIX_BK_HI_MASK 0x3FFFFFFFu
+#define AIX_BK_OVERFLOW 0x80000000u
+#define AIX_BK_EMPTY_HI 0x3FFFFFFFu
+#define AIX_BK_NONE 0xFFFFFFFFu
+
 // ---------------------------------------------------------------------------------------------
 // exact h % d for a launch-invariant d (Moeller-Granlund 2-by-1 division, 32-bit limbs).
 // gfx950 has no 64-bit integer divide; three of these replace the three `%` of mphf::lookup.
@@ -379,6 +397,66 @@ __device__ __forceinline__ uint64_t mphf_from_hash(const MphfDev& m, uint64_t a,
     uint32_t fps;
     uint64_t node;
     return mphf_from_hash_fp(m, a, b, c, fps, node);
+}
+
+// ---------------------------------------------------------------------------------------------
+// bucket table probe, wave-cooperative
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t bucket_of(uint64_t a, uint32_t nb) { return (uint32_t)__umul64hi(a, (uint64_t)nb); }   // nb < 2^32
+
+struct BkRes {
+    uint32_t found, tf, slot, overflow;
+};
+__device__ __forceinline__ uint32_t bperm(uint32_t src_lane, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v); }
+
+// All 64 lanes of the wave call this together (lanes without a probe pass want = false). LPP consecutive lanes share one
+// probe at a time: in round r the group reads the bucket of its r-th lane, each lane 128 / LPP bytes of the line, so a
+// wave-wide load instruction covers whole 128-byte lines (LPP = 8: eight lines per instruction, fully coalesced) instead of
+// 64 lanes pulling 16 bytes out of 64 different lines eight times over. All loads are issued before the first compare.
+template <int LPP>
+__device__ __forceinline__ BkRes bucket_probe_wave(const BkEntry* __restrict__ bk, uint32_t nb, bool want, uint64_t a, uint64_t code) {
+    constexpr int EPL = 8 / LPP;                                   // entries per lane and round
+    const uint32_t lane = __lane_id();
+    const uint32_t j = lane & (LPP - 1), gbase = lane & ~(uint32_t)(LPP - 1);
+    const uint32_t my_b = want ? bucket_of(a, nb) : AIX_BK_NONE;
+    const uint32_t my_lo = (uint32_t)code, my_hi = (uint32_t)(code >> 32);
+    uint4 e[LPP][EPL];
+    uint32_t bsrc[LPP];
+#pragma unroll
+    for (int r = 0; r < LPP; ++r) {
+        bsrc[r] = LPP == 1 ? my_b : bperm(gbase + r, my_b);
+        const uint4* p = (const uint4*)(bk + (uint64_t)(bsrc[r] != AIX_BK_NONE ? bsrc[r] : 0u) * 8 + j * EPL);   // bucket 0 is always there
+#pragma unroll
+        for (int t = 0; t < EPL; ++t) e[r][t] = p[t];
+    }
+    BkRes res{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int r = 0; r < LPP; ++r) {
+        const uint32_t c_lo = LPP == 1 ? my_lo : bperm(gbase + r, my_lo);
+        const uint32_t c_hi = LPP == 1 ? my_hi : bperm(gbase + r, my_hi);
+        const bool live = bsrc[r] != AIX_BK_NONE;
+        uint32_t h_tf = 0, h_slot = 0;
+        bool m = false;
+#pragma unroll
+        for (int t = 0; t < EPL; ++t) {
+            const bool mm = live && e[r][t].x == c_lo && (e[r][t].y & AIX_BK_HI_MASK) == c_hi;
+            if (mm) { m = true; h_tf = e[r][t].z; h_slot = e[r][t].w; }
+        }
+        const bool ov = live && j == (uint32_t)(LPP - 1) && (e[r][EPL - 1].y & AIX_BK_OVERFLOW);    // entry 7 of the line
+        if (LPP == 1) {
+            res.found = m; res.tf = h_tf; res.slot = h_slot; res.overflow = ov;
+        } else {
+            const uint64_t bal = __ballot(m), balov = __ballot(ov);
+            const uint32_t grp = (uint32_t)(bal >> gbase) & ((1u << LPP) - 1u);
+            const uint32_t ml = gbase + (grp ? (uint32_t)__builtin_ctz(grp) : 0u);
+            const uint32_t v_tf = bperm(ml, h_tf), v_slot = bperm(ml, h_slot);
+            if (j == (uint32_t)r) {
+                res.found = grp != 0u; res.tf = v_tf; res.slot = v_slot;
+                res.overflow = (uint32_t)(balov >> (gbase + LPP - 1)) & 1u;
+            }
+        }
+    }
+    return res;
 }
 
 }  // namespace aix

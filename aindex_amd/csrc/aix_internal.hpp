@@ -18,6 +18,9 @@ struct IndexDev {
     uint32_t k;
     uint32_t use_fp;          // 23-mer: the fingerprint nibbles of the MPHF records are populated
     uint32_t early_exit;      // 23-mer: presence masks populated and the early-exit walk enabled
+    const BkEntry* bk;        // 23-mer: verification table (nb buckets of 8 entries), nullptr when not built / switched off
+    uint32_t nb;
+    uint32_t bk_lpp;          // lanes that share one bucket read (8, 4, 2 or 1); launch-time choice
 };
 
 enum LookupMode { MODE_TF = 0, MODE_HASH = 1, MODE_KIDSTRAND = 2, MODE_BOTH = 3, MODE_TOTAL = 4, MODE_LINES = 5 };
@@ -46,6 +49,9 @@ hipError_t launch_coverage(const IndexDev& ix, const uint8_t* seqs, const uint64
 // index construction helpers
 hipError_t launch_build_keyrecs(const uint64_t* checker, const uint32_t* tf, uint64_t n, KeyRec* recs, uint32_t* noncanon_count, hipStream_t s);
 hipError_t launch_set_fingerprints(const MphfDev& m, BvRec* recs_rw, EeRec* ee_rw, const KeyRec* keys, uint64_t n, hipStream_t s);
+// verification table: bk (nb * 8 entries) is initialised and filled from the keys that sit in their own MPHF slot;
+// fill = nb zeroed u32 counters (scratch)
+hipError_t launch_build_buckets(const MphfDev& m, const KeyRec* keys, uint64_t n, BkEntry* bk, uint32_t nb, uint32_t* fill, hipStream_t s);
 hipError_t launch_scatter23(const MphfDev& m, uint64_t n, uint64_t nslots, const uint8_t* keys_ascii /* or */, const uint64_t* codes, const uint32_t* counts,
                             uint64_t* checker, uint32_t* tf, uint32_t* occupied_bits, uint32_t* conflict, hipStream_t s);
 hipError_t launch_perm13(const MphfDev& m, uint32_t* perm /* [4^13]: code -> mphf index */, hipStream_t s);

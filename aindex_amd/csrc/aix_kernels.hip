@@ -23,17 +23,15 @@ static inline unsigned grid_for(uint64_t work, unsigned per_block = kBlock) {
 struct Probe {
     uint64_t slot;
     uint32_t tf;
-    uint32_t lines;     // instrumentation for MODE_LINES: MPHF records read | 16 per key record read | 256 per completed evaluation
+    uint32_t lines;     // instrumentation for MODE_LINES: MPHF records read | 16 per key record read | 256 per completed evaluation | 65536 per bucket line
     bool found;
 };
-// hash the 23 ASCII bytes in (w0,w1,w2), evaluate the MPHF, verify against the stored code
+// MPHF path: evaluate the MPHF on the hash (a, b, c) of the probed bytes, verify against the stored code.
 // `filters`: the hashed bytes are exactly the ASCII of `code`. Only then do a stored key's fingerprint / presence
 // bits (computed from ITS ASCII) say anything about this probe; the reference's forward probe of a query with
 // non-ACGT bytes hashes the raw bytes but compares the sanitised code (python_wrapper.cpp:611-613) and can — by a
 // 1-in-n coincidence of slots — match a stored key whose hash is different, so that probe runs unfiltered.
-__device__ __forceinline__ Probe probe23(const IndexDev& ix, uint64_t w0, uint64_t w1, uint64_t w2, uint64_t code, bool filters = true) {
-    uint64_t a, b, c;
-    jenkins23(w0, w1, w2, ix.m.seed, a, b, c);
+__device__ __forceinline__ Probe probe23_mphf(const IndexDev& ix, uint64_t a, uint64_t b, uint64_t c, uint64_t code, bool filters) {
     Probe r;
     r.found = false;
     r.tf = 0;
@@ -62,17 +60,39 @@ __device__ __forceinline__ Probe probe23(const IndexDev& ix, uint64_t w0, uint64
     }
     return r;
 }
+// one lane on its own (ragged lengths, index construction): hash the 23 ASCII bytes in (w0,w1,w2), MPHF path
+__device__ __forceinline__ Probe probe23(const IndexDev& ix, uint64_t w0, uint64_t w1, uint64_t w2, uint64_t code, bool filters = true) {
+    uint64_t a, b, c;
+    jenkins23(w0, w1, w2, ix.m.seed, a, b, c);
+    return probe23_mphf(ix, a, b, c, code, filters);
+}
 // same, but the forward hash (a,b,c) was computed elsewhere (ragged lengths)
 __device__ __forceinline__ Probe probe23_hashed(const IndexDev& ix, uint64_t a, uint64_t b, uint64_t c, uint64_t code) {
+    return probe23_mphf(ix, a, b, c, code, false);
+}
+
+// The probe of the batch kernels. EVERY lane of the wave calls it (want = false: this lane has nothing to probe); with the
+// verification table on, a probe whose hashed bytes are the ASCII of `code` (filters) is answered from its bucket line, all
+// others — and an unmatched probe of an overflowed bucket — by the MPHF path.
+template <int LPP>
+__device__ __forceinline__ Probe probe23_wave(const IndexDev& ix, bool want, uint64_t w0, uint64_t w1, uint64_t w2, uint64_t code, bool filters = true) {
+    uint64_t a = 0, b = 0, c = 0;
+    if (want) jenkins23(w0, w1, w2, ix.m.seed, a, b, c);
     Probe r;
-    r.slot = mphf_from_hash(ix.m, a, b, c);
-    r.found = false;
-    r.tf = 0;
-    r.lines = 3 + 256;
-    if (r.slot < ix.n) {
-        const KeyRec k = ix.keys[r.slot];
-        r.lines += 16;
-        if (k.code == code) { r.found = true; r.tf = k.tf; }
+    r.found = false; r.tf = 0; r.slot = 0; r.lines = 0;
+    bool mphf = want;
+    if (ix.bk) {
+        const bool use = want && filters;
+        const BkRes k = bucket_probe_wave<LPP>(ix.bk, ix.nb, use, a, code);
+        if (use) {
+            r.lines = 65536;
+            if (k.found) { r.found = true; r.tf = k.tf; r.slot = k.slot; }
+            mphf = !k.found && k.overflow;
+        }
+    }
+    if (mphf) {
+        const Probe q = probe23_mphf(ix, a, b, c, code, filters);
+        r.found = q.found; r.tf = q.tf; r.slot = q.slot; r.lines += q.lines;
     }
     return r;
 }
@@ -84,113 +104,158 @@ struct Q23 {
     uint32_t strand;
     uint32_t lines;
 };
-template <bool CANON>
-__device__ __forceinline__ Q23 query23(const IndexDev& ix, uint64_t w0, uint64_t w1, uint64_t w2) {
+// wave-cooperative (all lanes call it; `active` = this lane holds a query)
+template <bool CANON, int LPP>
+__device__ __forceinline__ Q23 query23(const IndexDev& ix, bool active, uint64_t w0, uint64_t w1, uint64_t w2) {
     const Enc23 e = encode23_words(w0, w1, w2);
     const uint64_t r = revcomp(e.code, 23);
     Q23 out;
     out.slot = 0; out.tf = 0; out.strand = 0; out.lines = 0;
-    if (CANON && e.valid) {
-        // every stored code is canonical: only the canonical strand of the query can match. ONE probe call site: with the
-        // strands chosen per lane first, a wave runs Jenkins + the MPHF walk once, not once per strand with half its lanes idle
+    if (CANON) {
+        // every stored code is canonical: only the canonical strand of a pure-ACGT query can match. ONE probe call site: with the
+        // strands chosen per lane first, a wave runs Jenkins + the probe once, not once per strand with half its lanes idle
         const bool fwd = e.code <= r;
         uint64_t x0 = w0, x1 = w1, x2 = w2;
         if (!fwd) ascii23_of_rc(e.code, x0, x1, x2);
-        const Probe p = probe23(ix, x0, x1, x2, fwd ? e.code : r);
-        out.lines = p.lines;
-        if (p.found) { out.slot = p.slot; out.tf = p.tf; out.strand = fwd ? 1u : 2u; }
+        const Probe p = probe23_wave<LPP>(ix, active && e.valid, x0, x1, x2, fwd ? e.code : r);
+        if (active && e.valid) {
+            out.lines = p.lines;
+            if (p.found) { out.slot = p.slot; out.tf = p.tf; out.strand = fwd ? 1u : 2u; }
+        }
+        if (active && !e.valid) {                               // other bytes: the reference's two probes, lane by lane (rare)
+            uint64_t a, b, c;
+            jenkins23(w0, w1, w2, ix.m.seed, a, b, c);
+            const Probe f = probe23_mphf(ix, a, b, c, e.code, false);   // raw bytes hashed, sanitised code compared
+            out.lines = f.lines;
+            if (f.found) { out.slot = f.slot; out.tf = f.tf; out.strand = 1; }
+            else {
+                uint64_t r0, r1, r2;
+                ascii23_of_rc(e.code, r0, r1, r2);              // decode(reverseDNA(u)), :615-616
+                const Probe g = probe23(ix, r0, r1, r2, r);
+                out.lines += g.lines;
+                if (g.found) { out.slot = g.slot; out.tf = g.tf; out.strand = 2; }
+            }
+        }
         return out;
     }
-    const Probe f = probe23(ix, w0, w1, w2, e.code, e.valid);  // raw bytes hashed, sanitised code compared
-    out.lines = f.lines;
-    if (f.found) { out.slot = f.slot; out.tf = f.tf; out.strand = 1; return out; }
+    const Probe f = probe23_wave<LPP>(ix, active, w0, w1, w2, e.code, e.valid);   // raw bytes hashed, sanitised code compared
     uint64_t r0, r1, r2;
     ascii23_of_rc(e.code, r0, r1, r2);                          // decode(reverseDNA(u)), :615-616
-    const Probe g = probe23(ix, r0, r1, r2, r);
-    out.lines += g.lines;
-    if (g.found) { out.slot = g.slot; out.tf = g.tf; out.strand = 2; }
+    const Probe g = probe23_wave<LPP>(ix, active && !f.found, r0, r1, r2, r);
+    if (active) {
+        out.lines = f.lines;
+        if (f.found) { out.slot = f.slot; out.tf = f.tf; out.strand = 1; }
+        else {
+            out.lines += g.lines;
+            if (g.found) { out.slot = g.slot; out.tf = g.tf; out.strand = 2; }
+        }
+    }
     return out;
 }
 
-// get_tf_both_directions_23mer (python_wrapper.cpp:1259-1275): Q1(q) and Q1(decode(rc(q)))
-template <bool CANON>
-__device__ __forceinline__ void both23(const IndexDev& ix, uint64_t w0, uint64_t w1, uint64_t w2, uint32_t& fwd, uint32_t& rc) {
+// get_tf_both_directions_23mer (python_wrapper.cpp:1259-1275): Q1(q) and Q1(decode(rc(q))); wave-cooperative like query23
+template <bool CANON, int LPP>
+__device__ __forceinline__ void both23(const IndexDev& ix, bool active, uint64_t w0, uint64_t w1, uint64_t w2, uint32_t& fwd, uint32_t& rc) {
     const Enc23 e = encode23_words(w0, w1, w2);
     const uint64_t r = revcomp(e.code, 23);
-    if (CANON && e.valid) {
-        const Q23 q = query23<true>(ix, w0, w1, w2);
-        fwd = q.tf; rc = q.tf;
-        return;
-    }
-    uint64_t r0, r1, r2;
-    ascii23_of_rc(e.code, r0, r1, r2);
-    const Probe F = probe23(ix, w0, w1, w2, e.code, e.valid);
-    const Probe R = probe23(ix, r0, r1, r2, r);
-    Probe S = F;
-    if (!e.valid) {                                             // second call's fallback decodes the sanitised code
-        uint64_t s0, s1, s2;
-        ascii23_of_rc(r, s0, s1, s2);
-        S = probe23(ix, s0, s1, s2, e.code);
-    }
-    fwd = F.found ? F.tf : (R.found ? R.tf : 0u);
-    rc = R.found ? R.tf : (S.found ? S.tf : 0u);
-}
-
-template <int MODE, bool CANON>
-__global__ void __launch_bounds__(kBlock) k_lookup23_ascii(const IndexDev ix, const uint8_t* __restrict__ q, uint64_t N, LookupOut out) {
-    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += stride) {
-        uint64_t w0, w1, w2;
-        load23(q + 23 * i, w0, w1, w2);
-        if (MODE == MODE_TF) {
-            out.tf[i] = query23<CANON>(ix, w0, w1, w2).tf;
-        } else if (MODE == MODE_LINES) {
-            out.tf[i] = query23<CANON>(ix, w0, w1, w2).lines;   // instrumentation: records read for this query
-        } else if (MODE == MODE_HASH) {
+    fwd = 0; rc = 0;
+    const bool fast = CANON && e.valid;                         // canonical index, pure-ACGT query: both directions see the one canonical key
+    const Q23 q = query23<CANON, LPP>(ix, active && fast, w0, w1, w2);
+    if (active && fast) { fwd = q.tf; rc = q.tf; }
+    const bool slow = active && !fast;
+    if (CANON) {
+        if (slow) {                                             // non-ACGT bytes on a canonical index: lane by lane, MPHF path
+            uint64_t r0, r1, r2, s0, s1, s2;
+            ascii23_of_rc(e.code, r0, r1, r2);
+            ascii23_of_rc(r, s0, s1, s2);
             uint64_t a, b, c;
             jenkins23(w0, w1, w2, ix.m.seed, a, b, c);
-            out.u64a[i] = mphf_from_hash(ix.m, a, b, c);
+            const Probe F = probe23_mphf(ix, a, b, c, e.code, false);
+            const Probe R = probe23(ix, r0, r1, r2, r);
+            const Probe S = probe23(ix, s0, s1, s2, e.code);    // second call's fallback decodes the sanitised code
+            fwd = F.found ? F.tf : (R.found ? R.tf : 0u);
+            rc = R.found ? R.tf : (S.found ? S.tf : 0u);
+        }
+        return;
+    }
+    uint64_t r0, r1, r2, s0, s1, s2;
+    ascii23_of_rc(e.code, r0, r1, r2);
+    ascii23_of_rc(r, s0, s1, s2);
+    const Probe F = probe23_wave<LPP>(ix, slow, w0, w1, w2, e.code, e.valid);
+    const Probe R = probe23_wave<LPP>(ix, slow, r0, r1, r2, r);
+    const Probe S2 = probe23_wave<LPP>(ix, slow && !e.valid, s0, s1, s2, e.code);
+    if (slow) {
+        const Probe S = e.valid ? F : S2;
+        fwd = F.found ? F.tf : (R.found ? R.tf : 0u);
+        rc = R.found ? R.tf : (S.found ? S.tf : 0u);
+    }
+}
+
+// wave-uniform grid-stride loops: every lane of a wave runs the same number of trips (the probes are wave-cooperative)
+#define AIX_WAVE_LOOP(i, N)                                                                                    \
+    for (uint64_t i##_base = (uint64_t)blockIdx.x * kBlock + (threadIdx.x & ~63u), i = i##_base + (threadIdx.x & 63u); i##_base < (N); \
+         i##_base += (uint64_t)gridDim.x * kBlock, i += (uint64_t)gridDim.x * kBlock)
+
+template <int MODE, bool CANON, int LPP>
+__global__ void __launch_bounds__(kBlock) k_lookup23_ascii(const IndexDev ix, const uint8_t* __restrict__ q, uint64_t N, LookupOut out) {
+    AIX_WAVE_LOOP(i, N) {
+        const bool in = i < N;
+        uint64_t w0 = 0, w1 = 0, w2 = 0;
+        if (in) load23(q + 23 * i, w0, w1, w2);
+        if (MODE == MODE_TF) {
+            const uint32_t v = query23<CANON, LPP>(ix, in, w0, w1, w2).tf;
+            if (in) out.tf[i] = v;
+        } else if (MODE == MODE_LINES) {
+            const uint32_t v = query23<CANON, LPP>(ix, in, w0, w1, w2).lines;   // instrumentation: records read for this query
+            if (in) out.tf[i] = v;
+        } else if (MODE == MODE_HASH) {
+            if (in) {
+                uint64_t a, b, c;
+                jenkins23(w0, w1, w2, ix.m.seed, a, b, c);
+                out.u64a[i] = mphf_from_hash(ix.m, a, b, c);
+            }
         } else if (MODE == MODE_KIDSTRAND) {
-            const Q23 r = query23<CANON>(ix, w0, w1, w2);
-            if (out.u64a) out.u64a[i] = r.slot;                 // get_kid_by_kmer: 0 when absent (:700-716)
-            if (out.strand) out.strand[i] = (uint8_t)r.strand;
+            const Q23 r = query23<CANON, LPP>(ix, in, w0, w1, w2);
+            if (in) {
+                if (out.u64a) out.u64a[i] = r.slot;             // get_kid_by_kmer: 0 when absent (:700-716)
+                if (out.strand) out.strand[i] = (uint8_t)r.strand;
+            }
         } else {
             uint32_t f, r;
-            both23<CANON>(ix, w0, w1, w2, f, r);
-            if (MODE == MODE_TOTAL) {
-                out.u64a[i] = (uint64_t)f + (uint64_t)r;
-            } else {
-                if (out.u64a) out.u64a[i] = f;
-                if (out.u64b) out.u64b[i] = r;
+            both23<CANON, LPP>(ix, in, w0, w1, w2, f, r);
+            if (in) {
+                if (MODE == MODE_TOTAL) {
+                    out.u64a[i] = (uint64_t)f + (uint64_t)r;
+                } else {
+                    if (out.u64a) out.u64a[i] = f;
+                    if (out.u64b) out.u64b[i] = r;
+                }
             }
         }
     }
 }
 
-template <bool CANON>
+template <bool CANON, int LPP>
 __global__ void __launch_bounds__(kBlock) k_lookup23_codes(const IndexDev ix, const uint64_t* __restrict__ codes, uint64_t N, uint32_t* __restrict__ out) {
-    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += stride) {
-        const uint64_t u = codes[i] & ((1ULL << 46) - 1);
+    AIX_WAVE_LOOP(i, N) {
+        const bool in = i < N;
+        const uint64_t u = in ? (codes[i] & ((1ULL << 46) - 1)) : 0ull;
         const uint64_t r = revcomp(u, 23);
         uint64_t w0, w1, w2;
         uint32_t tf = 0;
         if (CANON) {
             const uint64_t key = u <= r ? u : r;
             ascii23_of_rc(u <= r ? r : u, w0, w1, w2);           // string of `key`
-            const Probe p = probe23(ix, w0, w1, w2, key);
+            const Probe p = probe23_wave<LPP>(ix, in, w0, w1, w2, key);
             tf = p.found ? p.tf : 0u;
         } else {
             ascii23_of_rc(r, w0, w1, w2);
-            const Probe f = probe23(ix, w0, w1, w2, u);
-            if (f.found) tf = f.tf;
-            else {
-                ascii23_of_rc(u, w0, w1, w2);
-                const Probe g = probe23(ix, w0, w1, w2, r);
-                tf = g.found ? g.tf : 0u;
-            }
+            const Probe f = probe23_wave<LPP>(ix, in, w0, w1, w2, u);
+            ascii23_of_rc(u, w0, w1, w2);
+            const Probe g = probe23_wave<LPP>(ix, in && !f.found, w0, w1, w2, r);
+            tf = f.found ? f.tf : (g.found ? g.tf : 0u);
         }
-        out[i] = tf;
+        if (in) out[i] = tf;
     }
 }
 
@@ -204,8 +269,16 @@ __global__ void __launch_bounds__(kBlock) k_lookup23_ragged(const IndexDev ix, c
         if (len >= 23) {
             uint64_t w0, w1, w2;
             load23(bytes + lo, w0, w1, w2);
-            if (len == 23) {
-                tf = query23<false>(ix, w0, w1, w2).tf;
+            if (len == 23) {                                     // lane by lane (lengths differ inside a wave): the MPHF path, both probes
+                const Enc23 e = encode23_words(w0, w1, w2);
+                const Probe f = probe23(ix, w0, w1, w2, e.code, e.valid);
+                if (f.found) tf = f.tf;
+                else {
+                    uint64_t r0, r1, r2;
+                    ascii23_of_rc(e.code, r0, r1, r2);
+                    const Probe g = probe23(ix, r0, r1, r2, revcomp(e.code, 23));
+                    tf = g.found ? g.tf : 0u;
+                }
             } else {
                 const Enc23 e = encode23_words(w0, w1, w2);
                 uint64_t a, b, c;
@@ -296,45 +369,48 @@ __global__ void __launch_bounds__(kBlock) k_lookup13_ragged(const IndexDev ix, c
 // ---------------------------------------------------------------------------------------------
 // coverage: one lane per byte position of the concatenated sequences (aindex.py:314-322)
 // ---------------------------------------------------------------------------------------------
-template <bool CANON>
+template <bool CANON, int LPP>
 __global__ void __launch_bounds__(kBlock) k_coverage(const IndexDev ix, const uint8_t* __restrict__ seqs, const uint64_t* __restrict__ offs, uint64_t M,
                                                     uint64_t total, uint32_t cutoff, uint32_t* __restrict__ out, const uint64_t* __restrict__ out_offs) {
-    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     const uint32_t k = ix.k;
-    for (uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x; p < total; p += stride) {
+    AIX_WAVE_LOOP(p, total) {
         // sequence containing byte p: largest s with offs[s] <= p. The lanes of a wave hold consecutive p, so the binary search
         // runs once per wave for its first position (wave-uniform: scalar loads), and a lane then walks forward from there —
         // zero or one step unless the sequences are shorter than a wave is wide (then a bounded walk, then its own search).
-        const uint64_t p0 = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(p >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)p);
+        const uint64_t p0 = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(p_base >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)p_base);
         uint64_t lo = 0, hi = M;                                // invariant offs[lo] <= p0 < offs[hi] (or lo == 0)
         while (hi - lo > 1) {
             const uint64_t mid = (lo + hi) >> 1;
             if (offs[mid] <= p0) lo = mid; else hi = mid;
         }
-        uint64_t s = lo;
-        for (int step = 0; step < 4 && s + 1 < M && offs[s + 1] <= p; ++step) ++s;
-        if (s + 1 < M && offs[s + 1] <= p) {
-            uint64_t l2 = s + 1, h2 = M;                        // offs[l2] <= p < offs[h2]
-            while (h2 - l2 > 1) {
-                const uint64_t mid = (l2 + h2) >> 1;
-                if (offs[mid] <= p) l2 = mid; else h2 = mid;
+        bool active = p < total;
+        uint64_t s = lo, begin = 0;
+        if (active) {
+            for (int step = 0; step < 4 && s + 1 < M && offs[s + 1] <= p; ++step) ++s;
+            if (s + 1 < M && offs[s + 1] <= p) {
+                uint64_t l2 = s + 1, h2 = M;                    // offs[l2] <= p < offs[h2]
+                while (h2 - l2 > 1) {
+                    const uint64_t mid = (l2 + h2) >> 1;
+                    if (offs[mid] <= p) l2 = mid; else h2 = mid;
+                }
+                s = l2;
             }
-            s = l2;
+            begin = offs[s];
+            const uint64_t end = offs[s + 1];
+            if (p < begin || p + k > end) active = false;       // p < begin: gaps between sequences are allowed
         }
-        const uint64_t begin = offs[s], end = offs[s + 1];
-        if (p < begin || p + k > end) continue;                 // p < begin: gaps between sequences are allowed
-        uint32_t tf;
+        uint32_t tf = 0;
         if (k == 23) {
-            uint64_t w0, w1, w2;
-            load23(seqs + p, w0, w1, w2);
-            tf = query23<CANON>(ix, w0, w1, w2).tf;
-        } else {
+            uint64_t w0 = 0, w1 = 0, w2 = 0;
+            if (active) load23(seqs + p, w0, w1, w2);
+            tf = query23<CANON, LPP>(ix, active, w0, w1, w2).tf;
+        } else if (active) {
             uint64_t w0, w1;
             load13(seqs + p, w0, w1);
             const Enc13 e = encode13_words(w0, w1);
             tf = e.valid ? (uint32_t)ix.tf13_code[e.code] : 0u;
         }
-        out[out_offs[s] + (p - begin)] = tf >= cutoff ? tf : 0u;
+        if (active) out[out_offs[s] + (p - begin)] = tf >= cutoff ? tf : 0u;
     }
 }
 
@@ -398,6 +474,42 @@ __global__ void __launch_bounds__(kBlock) k_set_fp(const MphfDev m, BvRec* __res
             if (sh > 20u) atomicOr(w + 1, q >> (32u - sh));
         }
     }
+}
+
+// Verification table (aix_device.hpp: BkEntry). Filed: every stored code that sits in its own MPHF slot, under the bucket its
+// Jenkins hash selects; the first eight arrivals of a bucket get an entry, the rest are left to the MPHF path (pass 2 raises
+// the bucket's overflow bit). Which eight is decided by the order of the atomics — the answers do not depend on it.
+__global__ void __launch_bounds__(kBlock) k_bk_init(BkEntry* __restrict__ bk, uint64_t nent) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < nent; i += stride) {
+        BkEntry e;
+        e.code_lo = 0xFFFFFFFFu; e.code_hi = AIX_BK_EMPTY_HI; e.tf = 0; e.slot = 0;
+        bk[i] = e;
+    }
+}
+__global__ void __launch_bounds__(kBlock) k_bk_fill(const MphfDev m, const KeyRec* __restrict__ keys, uint64_t n, BkEntry* __restrict__ bk, uint32_t nb,
+                                                   uint32_t* __restrict__ fill) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const KeyRec kr = keys[i];
+        if (kr.code >> 46) continue;
+        uint64_t w0, w1, w2, a, b, c;
+        ascii23_of_rc(revcomp(kr.code, 23), w0, w1, w2);
+        jenkins23(w0, w1, w2, m.seed, a, b, c);
+        if (mphf_from_hash(m, a, b, c) != i) continue;         // not where the MPHF puts it: the reference cannot find it, neither can a probe
+        const uint32_t bi = bucket_of(a, nb);
+        const uint32_t pos = atomicAdd(&fill[bi], 1u);
+        if (pos < 8u) {
+            BkEntry e;
+            e.code_lo = (uint32_t)kr.code; e.code_hi = (uint32_t)(kr.code >> 32); e.tf = kr.tf; e.slot = (uint32_t)i;
+            bk[(uint64_t)bi * 8 + pos] = e;
+        }
+    }
+}
+__global__ void __launch_bounds__(kBlock) k_bk_flag(BkEntry* __restrict__ bk, uint32_t nb, const uint32_t* __restrict__ fill) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t bi = (uint64_t)blockIdx.x * kBlock + threadIdx.x; bi < nb; bi += stride)
+        if (fill[bi] > 8u) bk[bi * 8 + 7].code_hi |= AIX_BK_OVERFLOW;
 }
 
 // I1 (hash.cpp:671-723): checker[h] = code, tf[h] = count with h = mphf(key). Keys arrive either as
@@ -494,27 +606,28 @@ __device__ __forceinline__ uint64_t u_to_t(uint64_t x) {
     const uint64_t nz = (((z & 0x7F7F7F7F7F7F7F7FULL) + 0x7F7F7F7F7F7F7F7FULL) | z) & 0x8080808080808080ULL;
     return x ^ ((~nz & 0x8080808080808080ULL) >> 7);
 }
+template <int LPP>
 __global__ void __launch_bounds__(kBlock) k_count23_fixed(const IndexDev ix, const uint8_t* __restrict__ buf, uint64_t len, int canon_mode, uint32_t* __restrict__ tf_out) {
-    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     if (len < 23) return;
     const uint64_t nwin = len - 22;
     IndexDev ixn = ix;
-    ixn.early_exit = 0;           // windows of reads drawn from the indexed genome are mostly hits: the parallel three-read evaluation; the
+    ixn.early_exit = 0;           // windows of reads drawn from the indexed genome are mostly hits. With the verification table: one line
+                                  // per window; without it (and for the overflow fall-back): the parallel three-read evaluation, whose
                                   // fingerprint (same 16 bytes as the pairs) still spares the key-record read of a window that is NOT a key
-    for (uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x; p < nwin; p += stride) {
-        uint64_t w0, w1, w2;
-        load23(buf + p, w0, w1, w2);
+    AIX_WAVE_LOOP(p, nwin) {
+        const bool in = p < nwin;
+        uint64_t w0 = 0, w1 = 0, w2 = 0;
+        if (in) load23(buf + p, w0, w1, w2);
         w0 = u_to_t(w0 & 0xDFDFDFDFDFDFDFDFULL);
         w1 = u_to_t(w1 & 0xDFDFDFDFDFDFDFDFULL);
         w2 = u_to_t(w2 & 0x00DFDFDFDFDFDFDFULL);
         const Enc23 e = encode23_words(w0, w1, w2);
-        if (!e.valid) continue;
         uint64_t key = e.code;
         if (canon_mode == 1) { const uint64_t x = revcomp_refx86(e.code, 23); key = e.code < x ? e.code : x; }
         else if (canon_mode == 2) { const uint64_t x = revcomp(e.code, 23); key = e.code < x ? e.code : x; }
         uint64_t s0, s1, s2;
         ascii23_of_rc(revcomp(key, 23), s0, s1, s2);
-        const Probe pr = probe23(ixn, s0, s1, s2, key);
+        const Probe pr = probe23_wave<LPP>(ixn, in && e.valid, s0, s1, s2, key);
         if (pr.found) atomicAdd(&tf_out[pr.slot], 1u);
     }
 }
@@ -672,15 +785,31 @@ __global__ void __launch_bounds__(kBlock) k_gather(const uint8_t* __restrict__ t
         return hipGetLastError();                                                    \
     } while (0)
 
+// lanes that share one bucket read: a launch-time choice (IndexDev::bk_lpp) among the instantiated widths
+#define AIX_LPP_SWITCH(lpp, CALL)          \
+    switch (lpp) {                          \
+        case 1: return CALL(1);             \
+        case 2: return CALL(2);             \
+        case 4: return CALL(4);             \
+        default: return CALL(8);            \
+    }
+template <bool CANON, int LPP>
+static hipError_t lookup23_tf(const IndexDev& ix, const uint8_t* q, uint64_t N, LookupOut out, hipStream_t s) {
+    AIX_LAUNCH((k_lookup23_ascii<MODE_TF, CANON, LPP>), N, s, ix, q, N, out);
+}
 template <bool CANON>
 static hipError_t lookup23_ascii_mode(const IndexDev& ix, const uint8_t* q, uint64_t N, int mode, LookupOut out, hipStream_t s) {
     switch (mode) {
-        case MODE_TF: AIX_LAUNCH((k_lookup23_ascii<MODE_TF, CANON>), N, s, ix, q, N, out);
-        case MODE_LINES: AIX_LAUNCH((k_lookup23_ascii<MODE_LINES, CANON>), N, s, ix, q, N, out);
-        case MODE_HASH: AIX_LAUNCH((k_lookup23_ascii<MODE_HASH, CANON>), N, s, ix, q, N, out);
-        case MODE_KIDSTRAND: AIX_LAUNCH((k_lookup23_ascii<MODE_KIDSTRAND, CANON>), N, s, ix, q, N, out);
-        case MODE_BOTH: AIX_LAUNCH((k_lookup23_ascii<MODE_BOTH, CANON>), N, s, ix, q, N, out);
-        case MODE_TOTAL: AIX_LAUNCH((k_lookup23_ascii<MODE_TOTAL, CANON>), N, s, ix, q, N, out);
+        case MODE_TF: {
+#define AIX_CALL(L) lookup23_tf<CANON, L>(ix, q, N, out, s)
+            AIX_LPP_SWITCH(ix.bk_lpp, AIX_CALL)
+#undef AIX_CALL
+        }
+        case MODE_LINES: AIX_LAUNCH((k_lookup23_ascii<MODE_LINES, CANON, 8>), N, s, ix, q, N, out);
+        case MODE_HASH: AIX_LAUNCH((k_lookup23_ascii<MODE_HASH, CANON, 8>), N, s, ix, q, N, out);
+        case MODE_KIDSTRAND: AIX_LAUNCH((k_lookup23_ascii<MODE_KIDSTRAND, CANON, 8>), N, s, ix, q, N, out);
+        case MODE_BOTH: AIX_LAUNCH((k_lookup23_ascii<MODE_BOTH, CANON, 8>), N, s, ix, q, N, out);
+        case MODE_TOTAL: AIX_LAUNCH((k_lookup23_ascii<MODE_TOTAL, CANON, 8>), N, s, ix, q, N, out);
     }
     return hipErrorInvalidValue;
 }
@@ -690,8 +819,8 @@ hipError_t launch_lookup23_ascii(const IndexDev& ix, const uint8_t* q, uint64_t 
 }
 hipError_t launch_lookup23_codes(const IndexDev& ix, const uint64_t* codes, uint64_t N, uint32_t* out, hipStream_t s) {
     if (N == 0) return hipSuccess;
-    if (ix.canonical_only) AIX_LAUNCH(k_lookup23_codes<true>, N, s, ix, codes, N, out);
-    AIX_LAUNCH(k_lookup23_codes<false>, N, s, ix, codes, N, out);
+    if (ix.canonical_only) AIX_LAUNCH((k_lookup23_codes<true, 8>), N, s, ix, codes, N, out);
+    AIX_LAUNCH((k_lookup23_codes<false, 8>), N, s, ix, codes, N, out);
 }
 hipError_t launch_lookup23_ragged(const IndexDev& ix, const uint8_t* bytes, const uint64_t* offs, uint64_t N, uint32_t* out, hipStream_t s) {
     if (N == 0) return hipSuccess;
@@ -710,11 +839,20 @@ hipError_t launch_lookup13_ragged(const IndexDev& ix, const uint8_t* bytes, cons
     if (N == 0) return hipSuccess;
     AIX_LAUNCH(k_lookup13_ragged, N, s, ix, bytes, offs, N, out);
 }
+template <bool CANON, int LPP>
+static hipError_t coverage_lpp(const IndexDev& ix, const uint8_t* seqs, const uint64_t* offs, uint64_t M, uint64_t total, uint32_t cutoff, uint32_t* out,
+                               const uint64_t* out_offs, hipStream_t s) {
+    AIX_LAUNCH((k_coverage<CANON, LPP>), total, s, ix, seqs, offs, M, total, cutoff, out, out_offs);
+}
 hipError_t launch_coverage(const IndexDev& ix, const uint8_t* seqs, const uint64_t* offs, uint64_t M, uint64_t total, uint32_t cutoff, uint32_t* out,
                            const uint64_t* out_offs, hipStream_t s) {
     if (M == 0 || total == 0) return hipSuccess;
-    if (ix.k == 23 && ix.canonical_only) AIX_LAUNCH(k_coverage<true>, total, s, ix, seqs, offs, M, total, cutoff, out, out_offs);
-    AIX_LAUNCH(k_coverage<false>, total, s, ix, seqs, offs, M, total, cutoff, out, out_offs);
+    if (ix.k == 23 && ix.canonical_only) {
+#define AIX_CALL(L) coverage_lpp<true, L>(ix, seqs, offs, M, total, cutoff, out, out_offs, s)
+        AIX_LPP_SWITCH(ix.bk_lpp, AIX_CALL)
+#undef AIX_CALL
+    }
+    return coverage_lpp<false, 8>(ix, seqs, offs, M, total, cutoff, out, out_offs, s);
 }
 hipError_t launch_build_keyrecs(const uint64_t* checker, const uint32_t* tf, uint64_t n, KeyRec* recs, uint32_t* noncanon, hipStream_t s) {
     if (n == 0) return hipSuccess;
@@ -728,6 +866,12 @@ hipError_t launch_set_fingerprints(const MphfDev& m, BvRec* recs_rw, EeRec* ee_r
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_init_ee, dim3(grid_for(m.nrecs)), dim3(kBlock), 0, s, (const BvRec*)recs_rw, m.nrecs, ee_rw);
     AIX_LAUNCH(k_set_fp, n, s, m, recs_rw, ee_rw, keys, n);
+}
+hipError_t launch_build_buckets(const MphfDev& m, const KeyRec* keys, uint64_t n, BkEntry* bk, uint32_t nb, uint32_t* fill, hipStream_t s) {
+    if (n == 0 || nb == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_bk_init, dim3(grid_for((uint64_t)nb * 8)), dim3(kBlock), 0, s, bk, (uint64_t)nb * 8);
+    hipLaunchKernelGGL(k_bk_fill, dim3(grid_for(n)), dim3(kBlock), 0, s, m, keys, n, bk, nb, fill);
+    AIX_LAUNCH(k_bk_flag, nb, s, bk, nb, (const uint32_t*)fill);
 }
 hipError_t launch_scatter23(const MphfDev& m, uint64_t n, uint64_t nslots, const uint8_t* keys, const uint64_t* codes, const uint32_t* counts, uint64_t* checker, uint32_t* tf,
                             uint32_t* occupied, uint32_t* conflict, hipStream_t s) {
@@ -750,9 +894,15 @@ hipError_t launch_scatter13_to_mphf(const uint32_t* perm, const unsigned long lo
 hipError_t launch_perm13_check(const uint32_t* perm, uint32_t* bits, uint32_t* bad, hipStream_t s) {
     AIX_LAUNCH(k_perm13_check, 67108864ull, s, perm, bits, bad);
 }
+template <int LPP>
+static hipError_t count23_lpp(const IndexDev& ix, const uint8_t* buf, uint64_t len, int canon_mode, uint32_t* tf_out, hipStream_t s) {
+    AIX_LAUNCH(k_count23_fixed<LPP>, len - 22, s, ix, buf, len, canon_mode, tf_out);
+}
 hipError_t launch_count23_fixed(const IndexDev& ix, const uint8_t* buf, uint64_t len, int canon_mode, uint32_t* tf_out, hipStream_t s) {
     if (len < 23 || ix.n == 0) return hipSuccess;
-    AIX_LAUNCH(k_count23_fixed, len - 22, s, ix, buf, len, canon_mode, tf_out);
+#define AIX_CALL(L) count23_lpp<L>(ix, buf, len, canon_mode, tf_out, s)
+    AIX_LPP_SWITCH(ix.bk_lpp, AIX_CALL)
+#undef AIX_CALL
 }
 hipError_t launch_window_codes(const uint8_t* buf, uint64_t len, int k, int canon_mode, uint64_t* out, hipStream_t s) {
     if (len < (uint64_t)k) return hipSuccess;

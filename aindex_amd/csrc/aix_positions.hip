@@ -34,36 +34,47 @@ __global__ void __launch_bounds__(kB) k_tf_u64(const KeyRec* __restrict__ recs, 
     for (uint64_t i = (uint64_t)blockIdx.x * kB + threadIdx.x; i <= n; i += stride) tf64[i] = i < n ? (uint64_t)recs[i].tf : 0ull;
 }
 
-// bucket of every window (key = n for "no bucket"): hash.cpp:1004-1052
+// bucket of every window (key = n for "no bucket"): hash.cpp:1004-1052. Wave-uniform loop: the verification-table probe is
+// wave-cooperative (aix_device.hpp: bucket_probe_wave); a forward-strand window with bytes outside ACGT hashes its RAW bytes
+// (:1032-1040), which the table cannot answer, and goes through the MPHF.
 __global__ void __launch_bounds__(kB) k_a2_probe(const IndexDev ix, const uint8_t* __restrict__ buf, uint64_t nwin, uint64_t start, uint32_t* __restrict__ keys) {
     const uint64_t stride = (uint64_t)gridDim.x * kB;
     const uint64_t FULL = ~0ULL, LAST7 = 0x00FFFFFFFFFFFFFFULL;
-    for (uint64_t i = (uint64_t)blockIdx.x * kB + threadIdx.x; i < nwin; i += stride) {
+    for (uint64_t base = (uint64_t)blockIdx.x * kB + (threadIdx.x & ~63u); base < nwin; base += stride) {
+        const uint64_t i = base + (threadIdx.x & 63u);
+        const bool in = i < nwin;
         uint32_t key = (uint32_t)ix.n;
-        if (i >= start) {
-            uint64_t w0, w1, w2;
+        uint64_t w0 = 0, w1 = 0, w2 = 0;
+        bool probe = false;
+        if (in && i >= start) {
             load23(buf + i, w0, w1, w2);
             const bool skip = has_byte(w0, '\n', FULL) || has_byte(w1, '\n', FULL) || has_byte(w2, '\n', LAST7) ||
                               has_byte(w0, '~', FULL) || has_byte(w1, '~', FULL) || has_byte(w2, '~', LAST7) ||
                               has_byte(w0, 'N', FULL) || has_byte(w1, 'N', FULL) || has_byte(w2, 'N', LAST7);      // :1006-1011
-            if (!skip) {
-                const Enc23 e = encode23_words(w0, w1, w2);                    // get_dna23_bitset: non-ACGT -> 0
-                const uint64_t r = revcomp(e.code, 23);
-                uint64_t a, b, c, want;
-                if (e.code <= r) {                                            // :1032: probe the numerically smaller strand only
-                    jenkins23(w0, w1, w2, ix.m.seed, a, b, c);                 // raw bytes of the window
-                    want = e.code;
-                } else {
-                    uint64_t r0, r1, r2;
-                    ascii23_of_rc(e.code, r0, r1, r2);
-                    jenkins23(r0, r1, r2, ix.m.seed, a, b, c);
-                    want = r;
-                }
-                const uint64_t h = mphf_from_hash(ix.m, a, b, c);
-                if (h < ix.n && ix.keys[h].code == want) key = (uint32_t)h;
+            probe = !skip;
+        }
+        const Enc23 e = encode23_words(w0, w1, w2);                            // get_dna23_bitset: non-ACGT -> 0
+        const uint64_t r = revcomp(e.code, 23);
+        const bool fwd = e.code <= r;                                           // :1032: probe the numerically smaller strand only
+        const uint64_t want = fwd ? e.code : r;
+        uint64_t x0 = w0, x1 = w1, x2 = w2;                                     // forward: the raw bytes of the window
+        if (!fwd) ascii23_of_rc(e.code, x0, x1, x2);
+        uint64_t a = 0, b = 0, c = 0;
+        if (probe) jenkins23(x0, x1, x2, ix.m.seed, a, b, c);
+        const bool tab = probe && (e.valid || !fwd);                            // the hashed bytes are the ASCII of `want`
+        bool mphf = probe;
+        if (ix.bk) {
+            const BkRes k = bucket_probe_wave<8>(ix.bk, ix.nb, tab, a, want);
+            if (tab) {
+                if (k.found) key = k.slot;
+                mphf = !k.found && k.overflow;
             }
         }
-        keys[i] = key;
+        if (mphf) {
+            const uint64_t h = mphf_from_hash(ix.m, a, b, c);
+            if (h < ix.n && ix.keys[h].code == want) key = (uint32_t)h;
+        }
+        if (in) keys[i] = key;
     }
 }
 

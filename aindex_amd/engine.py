@@ -151,6 +151,18 @@ class Index:
     def set_early_exit(self, enabled: bool):
         check(lib().aix_index_set_early_exit(self._h, int(enabled)))
 
+    def set_bucket_table(self, enabled: bool, lanes: int = 0):
+        """Verification table on / off (answers are identical); lanes = lanes sharing one bucket read (8, 4, 2, 1; 0 = keep)."""
+        check(lib().aix_index_set_bucket_table(self._h, int(enabled), lanes))
+
+    def probe_profile(self) -> dict:
+        """What one probe that FINDS its key reads under the current settings (bench.py's roofline accounting)."""
+        i = self.info
+        if i["bucket_table"]:
+            return {"name": f"verification table: one 128-byte bucket line per probe ({i['bucket_lanes']} lanes per line)",
+                    "bytes_per_hit_probe": 128.0, "lines_per_hit_probe": 1.0}
+        return {"name": "three 16-byte MPHF records + one 16-byte key record", "bytes_per_hit_probe": 64.0, "lines_per_hit_probe": 4.0}
+
     def set_tf_13(self, tf: np.ndarray):
         tf = np.ascontiguousarray(tf, dtype=np.uint64)
         assert tf.shape[0] == _lib.TOTAL_13MERS

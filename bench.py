@@ -8,9 +8,15 @@ queries (already in HBM) through aix_tf_batch_ascii_dev. N > 1: every rank holds
 and its own 100 M queries (weak scaling, no data-path collective).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N                      (N > 1 without a torchrun environment: starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Other workloads (own measurements, same JSON shape): --workload count13 | count23 | lookup13.
+N > 1 measures what actually scales (BASELINE.json configs[3]): `--total-reads` (200 M) synthetic 150 bp reads
+of seed 41 cut into N contiguous read ranges, every rank histograms its range against the fixed 23-mer MPHF index in its own
+HBM, ONE RCCL all-reduce(sum) of tf[n]; total work fixed ("scaling": "strong"). The N = 1 line carries the same measurement
+under secondary.count23_strong, so the curve is value(N) / secondary.count23_strong.value(1).
+
+Other workloads (own measurements, same JSON shape): --workload count13 | count23 | lookup13 | coverage23 | ...
 """
 import argparse
 import json
@@ -301,13 +307,247 @@ def cpu_baseline_coverage23(ix, pf, seqs_t, L, out_t, per, n_seq, tmpdir):
     return res
 
 
-def load_pmc_traffic(workload):
+def load_pmc_traffic(key, **must_match):
+    """PMC-measured HBM-side bytes per launch (profiles/pmc_traffic.json, filled from the rocprofv3 --pmc passes of
+    scripts/gpu_profile_all.sh). Attached only when the entry was measured with the same per-launch size and settings as this
+    run; anything else gets None (a stale figure is worse than none)."""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
-        d = json.load(open(p))
-        return d.get(workload)
+        e = json.load(open(p)).get(key)
     except Exception:
         return None
+    if not e:
+        return None
+    for k, v in must_match.items():
+        if e.get(k) != v:
+            return None
+    return e
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(a, argv):
+    """`bench.py --gpus N` (N > 1) outside a torchrun environment: start the N ranks as a CHILD process (torch.distributed.run,
+    one rank per GPU, rendezvous on 127.0.0.1), hand its single JSON line on and leave with its status. This process has not
+    touched the GPU (device_count() does not initialise it), and nothing is exec'd."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if a.workload != "selftest":
+        import torch
+        have = torch.cuda.device_count()
+        if have < a.gpus and not env.get("AIX_BENCH_ONE_DEVICE"):
+            # fewer devices than ranks (a 1-GPU box): rehearsal mode — every rank on device 0, gloo collectives. The JSON says so.
+            log(f"bench.py: {have} device(s) for {a.gpus} ranks: rehearsal mode (AIX_BENCH_ONE_DEVICE=1, gloo)")
+            env["AIX_BENCH_ONE_DEVICE"] = "1"
+        if env.get("AIX_BENCH_ONE_DEVICE"):
+            env.setdefault("AIX_DIST_BACKEND", "gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    log("bench.py: launching", " ".join(cmd))
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{") and '"metric"' in ln]
+    if lines:
+        print(lines[-1], flush=True)
+    elif r.returncode == 0:
+        log("bench.py: the ranks printed no JSON line")
+        return 1
+    return r.returncode
+
+
+def tf_checksum(tf_t):
+    """Two order-independent digests of a tf[] histogram (device tensor of u32 bit patterns): the plain sum and a
+    position-weighted sum mod 2^63. Equal digests at N = 1 and N = 8 <=> the sharded + all-reduced histogram is the unsharded one."""
+    import torch
+    t = tf_t.to(torch.int64) & 0xFFFFFFFF
+    w = (torch.arange(t.numel(), dtype=torch.int64, device=t.device) % 1000003) + 1
+    return {"sum": int(t.sum().item()), "weighted": int(((t * w).sum() & 0x7FFFFFFFFFFFFFFF).item())}
+
+
+def measure_lookup23(ix, g, qset, queries, rank, world, dev, steps, warmup, gather_probe):
+    """One query set of SURVEY 8(d) through aix_tf_batch_ascii_dev: Q_rand = uniform-random 23-mers (seed 7; ~all absent),
+    Q_mix = 50 % genome windows on a random strand + 50 % random (seed 8). Queries are generated in HBM; every rank its own."""
+    import torch
+    from aindex_amd import engine
+    if qset == "Q_mix":
+        q = engine.synth_mix23_t(8, g, queries, first=rank * queries)
+    else:
+        q = engine.synth_kmers_t(7, queries, 23, dev, first=rank * queries)
+    res = torch.empty(queries, dtype=torch.int32, device=f"cuda:{dev}")
+    wall, kern_ms, _ = timed_steps(lambda: ix.tf_ascii_t(q, res), steps, warmup, dev)
+    hf = int((res != 0).sum().item()) / queries
+    info = ix.info
+    # what the kernel touches (instrumented launch of the same kernel, same settings), per query: MPHF records, key records,
+    # evaluations carried through to the rank, bucket lines of the verification table
+    li = ix.lines_ascii_t(q).to(torch.int64)
+    mphf_recs = float((li & 15).sum().item()) / queries
+    key_recs = float(((li >> 4) & 15).sum().item()) / queries
+    completed = float(((li >> 8) & 255).sum().item()) / queries
+    bucket_lines = float((li >> 16).sum().item()) / queries
+    del li
+    t = kern_ms * 1e-3
+    # bytes this kernel REQUESTS: the query in and the answer out (23 + 4), 128 per bucket line, 12 per record of the early-exit
+    # walk (pairs + prefix + the presence dword) or 16 per record of the parallel evaluation, 16 per key record
+    rec_bytes = 12.0 if info_flag(ix, "early_exit") else 16.0
+    requested = 27.0 + 128.0 * bucket_lines + rec_bytes * mphf_recs + 16.0 * key_recs
+    lines = bucket_lines + mphf_recs + key_recs
+    ach = requested * queries / t / 1e9
+    line_gbs = (lines * 128.0 + 27.0) * queries / t / 1e9
+    # the reference algorithm's bytes for the same queries (SURVEY 8d: 104 B forward hit, 204 B reverse hit, 200 B miss, + 27 B streamed)
+    ref_bytes = 27.0 + (200.0 * (1.0 - hf) + 154.0 * hf)
+    roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "kernel": "k_lookup23_ascii", "kernel_ms": kern_ms, "queries_per_launch": queries,
+            "requested_bytes_per_query": requested,
+            "note": "achieved = bytes the kernel requests (27 streamed + 128 per bucket line + 12/16 per MPHF record + 16 per key record, as "
+                    "counted by an instrumented launch) x queries / launch time; every random access moves a whole 128-byte line, see line_traffic",
+            "line_traffic": {"GBps": line_gbs, "frac": line_gbs / HBM_PEAK_GBS, "lines_per_query": lines,
+                             "note": "128-byte lines x accesses + streamed bytes, per second (estimate from the instrumented launch; `traffic` is the "
+                                     "PMC figure: fabric-side bytes, Infinity-Cache hits included)"},
+            "reference_algorithm": {"bytes_per_query": ref_bytes, "GBps": ref_bytes * queries / t / 1e9,
+                                    "note": "SURVEY 8(d): what mphf::lookup x probes + checker + tf would move for these queries — for orientation, "
+                                            "NOT what this kernel moves (no frac is derived from it)"}}
+    if gather_probe:
+        peak_acc = gather_roofline(dev)
+        acc = lines * queries / t
+        roof["random_read"] = {"peak_accesses_per_s": peak_acc, "achieved_accesses_per_s": acc, "frac": acc / peak_acc, "accesses_per_query": lines,
+                               "note": "north_star's yardstick: peak = k_gather, uniform-random 16-byte reads over a 4 GiB table in HBM (SURVEY 8d-ii), "
+                                       "measured in this run; accesses served by L2 / Infinity Cache can push the ratio above 1"}
+    tr = load_pmc_traffic("lookup23:" + qset, queries_per_launch=queries, bucket_table=int(info["bucket_table"]))
+    if tr:
+        roof["traffic"] = tr.get("bytes_per_launch")
+        roof["traffic_source"] = tr.get("source")
+    cfg = {"workload": f"configs[2]: 23-mer batch lookup (aix_tf_batch_ascii_dev), {qset}: " +
+                       ("50 % windows of the indexed genome on a random strand + 50 % uniform-random 23-mers (seed 8)" if qset == "Q_mix"
+                        else "uniform-random 23-mer ASCII queries (seed 7)") + ", resident in HBM",
+           "query_set": qset, "query_seed": 8 if qset == "Q_mix" else 7, "queries_per_step_per_gpu": queries, "index_keys": ix.n,
+           "hit_fraction": hf, "bucket_table": bool(info["bucket_table"]), "bucket_lanes": info["bucket_lanes"], "buckets": info["buckets"],
+           "bucket_unfiled_keys": info["bucket_unfiled_keys"], "canonical_only": bool(info["canonical_only"]),
+           "bucket_lines_per_query": bucket_lines, "mphf_records_read_per_query": mphf_recs, "key_records_read_per_query": key_recs,
+           "completed_evaluations_per_query": completed, "index_hbm_bytes": info["device_bytes"]}
+    return {"value": world * queries * steps / wall, "ms_per_step": wall / steps * 1e3, "roofline": roof, "config": cfg, "_q": q, "_res": res}
+
+
+_FLAGS = {}
+
+
+def apply_ab_switches(ix, a):
+    if a.no_fastpath:
+        ix.set_canonical_fastpath(False)
+    if a.no_fingerprint:
+        ix.set_fingerprint_filter(False)
+    if a.no_early_exit:
+        ix.set_early_exit(False)
+        _FLAGS[(id(ix), "early_exit")] = False
+    if a.no_bucket_table or a.bucket_lanes:
+        ix.set_bucket_table(not a.no_bucket_table, a.bucket_lanes)
+
+
+def info_flag(ix, name):
+    """Host-side mirror of the A/B switches bench.py itself flipped (the library does not report them back)."""
+    return _FLAGS.get((id(ix), name), True)
+
+
+def count23_roofline(ix, windows, reads, kern_ms):
+    """Roofline object of k_count23_fixed. `achieved` = the bytes the kernel REQUESTS (its own record sizes) per launch / the
+    launch's duration: 151/128 input bytes per window (each byte is fetched once from HBM, re-reads by the neighbouring lanes
+    hit L1), one probe of the verification table per valid window, one 4-byte counter RMW (4 read + 4 written, memory side).
+    The reference algorithm's figure for the same windows (1.17 + 154 + 8 B) is kept beside it for orientation."""
+    p = ix.probe_profile()
+    per_window = 151.0 / 128.0 + p["bytes_per_hit_probe"] + 8.0
+    achieved = windows * per_window / (kern_ms * 1e-3) / 1e9
+    lines = p["lines_per_hit_probe"]
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "kernel": "k_count23_fixed", "kernel_ms": kern_ms, "requested_bytes_per_window": per_window, "lines_per_window": lines,
+            "windows_per_launch": windows, "reads_per_launch": reads, "probe": p["name"],
+            "line_traffic_estimate": {"GBps": windows * (lines * 128.0 + 151.0 / 128.0 + 128.0) / (kern_ms * 1e-3) / 1e9,
+                                      "note": "128-byte lines the probes and the counter RMW move (estimate; `traffic` is the PMC figure)"},
+            "reference_algorithm": {"bytes_per_window": 1.17 + 154.0 + 8.0,
+                                    "GBps": windows * (1.17 + 154.0 + 8.0) / (kern_ms * 1e-3) / 1e9,
+                                    "note": "SURVEY 8(d): what mphf::lookup + checker + tf would move per window; not what this kernel moves"}}
+
+
+def cpu_baseline_count23(ix, g, pf, dev, cache, ns=100_000):
+    """The reference has no tool for this composition (kmer_counter -> compute_index would re-derive the key set); the CPU path
+    timed beside it is the C restatement of the same histogram (forward-then-rc MPHF probes per window), 1 thread, on the first
+    `ns` reads of the workload, compared with the GPU histogram of the same reads."""
+    import torch
+    from aindex_amd import engine, _lib
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    tmpd = os.path.join(cache, "cpu23c")
+    os.makedirs(tmpd, exist_ok=True)
+    prefix = os.path.join(tmpd, "c23")
+    open(prefix + ".pf", "wb").write(pf)
+    ix.tf_array().tofile(prefix + ".tf.bin")
+    ix.checker_array().tofile(prefix + ".kmers.bin")
+    orc = O.OracleIndex23.from_prefix(prefix)
+    sample = engine.synth_reads_t(41, g, ns, 150, rc_half=True, n_rate_ppm=1000, first_read=0)
+    gpu_s = torch.zeros(ix.n, dtype=torch.int32, device=f"cuda:{dev}")
+    ix.count23_fixed_t(sample, _lib.CANON_TRUE_RC, gpu_s)
+    t0 = time.perf_counter(); want = orc.count23_fixed(sample.cpu().numpy().tobytes(), False, 2); dt = time.perf_counter() - t0
+    assert np.array_equal(want, gpu_s.cpu().numpy().view(np.uint32)), "CPU port and GPU disagree on the sample"
+    del orc
+    for f in (".pf", ".tf.bin", ".kmers.bin"):
+        os.remove(prefix + f)
+    return {"value": ns / dt, "unit": "reads/s", "cores": 1, "kind": "port", "sample": f"first {ns} reads of the workload (seed 41)"}
+
+
+def measure_count23_strong(ix, g, rank, world, dev, total_reads, steps, warmup):
+    """BASELINE configs[3] / SURVEY 8(d) config 4: `total_reads` reads x 150 bp (seed 41, 50 % reverse strand, 0.1 % N) cut
+    into `world` contiguous read ranges; rank r generates ITS range in its own HBM (nothing comes from the host), histograms it
+    against the fixed MPHF index (k_count23_fixed, true canonical form) and ONE all-reduce(sum) merges tf[n] (RCCL over xGMI
+    under "nccl"). Total work is fixed as `world` grows."""
+    import torch
+    from aindex_amd import dist as adist, engine, _lib
+    lo, hi = adist.shard_range(total_reads, rank, world)
+    reads = engine.synth_reads_t(41, g, hi - lo, 150, rc_half=True, n_rate_ppm=1000, first_read=lo)
+    tf = torch.zeros(ix.n, dtype=torch.int32, device=f"cuda:{dev}")
+    step = lambda: adist.count23_sharded_t(ix, reads, _lib.CANON_TRUE_RC, tf)
+    wall, kern_ms, _ = timed_steps(step, steps, warmup, dev)
+    digest = tf_checksum(tf)
+    ar_ms = 0.0
+    if world > 1 or os.environ.get("AIX_FORCE_DIST"):
+        scratch = tf.clone()
+        w_ar, _, _ = timed_steps(lambda: adist.all_reduce_sum_(scratch), 3, 1, dev)
+        ar_ms = w_ar / 3 * 1e3
+        del scratch
+    # kernel alone on this rank's share (no zeroing, no collective): the figure the roofline object is built from
+    k_only, k_ms, _ = timed_steps(lambda: ix.count23_fixed_t(reads, _lib.CANON_TRUE_RC, tf), 2, 0, dev)
+    del reads
+    import torch.distributed as dist
+    backend = dist.get_backend() if (dist.is_available() and dist.is_initialized()) else "none"
+    windows_rank = (hi - lo) * (150 - 22)
+    return {"metric": "reads_per_sec_23mer_count_fixed_mphf", "value": total_reads * steps / wall, "unit": "reads/s",
+            "scaling": "strong", "total_reads": total_reads, "reads_this_rank": hi - lo, "ms_per_step": wall / steps * 1e3,
+            "allreduce_ms": ar_ms, "allreduce_bytes": 4 * ix.n, "collective": f"all_reduce(sum) of int32 tf[{ix.n}]" if backend != "none" else "none (1 rank)",
+            "backend": backend, "collective_ranks": world if backend != "none" else 1,
+            "kernel": "k_count23_fixed", "kernel_ms_this_rank": k_ms, "windows_this_rank": windows_rank,
+            "windows_counted_all_ranks": digest["sum"], "tf_digest": digest,
+            "one_device_rehearsal": bool(os.environ.get("AIX_BENCH_ONE_DEVICE"))}
+
+
+def run_selftest(a, real_stdout):
+    """Launcher / rendezvous check that needs no GPU: `world` gloo ranks all-reduce their rank numbers; rank 0 prints the line."""
+    import torch
+    import torch.distributed as dist
+    from aindex_amd import dist as adist
+    rank, world, _ = adist.init("gloo")
+    if os.environ.get("AIX_SELFTEST_FAIL_RANK") == str(rank):      # test hook: a rank that dies must fail the whole launch
+        raise SystemExit(7)
+    t = torch.tensor([rank + 1], dtype=torch.int64)
+    adist.all_reduce_sum_(t)
+    assert int(t.item()) == world * (world + 1) // 2
+    if rank == 0:
+        os.write(real_stdout, (json.dumps({"metric": "selftest_ranks", "value": world, "unit": "ranks", "n_gpus": world, "steps": a.steps,
+                                           "warmup": a.warmup, "config": {"workload": "launcher self-test (gloo all-reduce on CPU tensors)"}}) + "\n").encode())
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -315,7 +555,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="lookup23", choices=["lookup23", "lookup13", "count13", "count23", "gather", "coverage23", "coverage13", "positions23", "normalize", "distinct23"])
+    ap.add_argument("--workload", default="auto", choices=["auto", "lookup23", "lookup13", "count13", "count23", "gather", "coverage23", "coverage13", "positions23", "normalize", "distinct23", "selftest"],
+                    help="auto: N = 1 -> lookup23 (BASELINE configs[2], the headline), N > 1 -> count23 --scaling strong (configs[3])")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"], help="count23: strong = --total-reads split over the ranks (config 4); weak = --reads per rank")
+    ap.add_argument("--total-reads", type=int, default=200_000_000, help="reads of the strong-scaling counting workload (config 4: 200 M)")
     ap.add_argument("--seqs", type=int, default=100_000)
     ap.add_argument("--seq-len", type=int, default=10_000)
     ap.add_argument("--table-mib", type=int, default=4096)
@@ -334,12 +577,27 @@ def main():
     ap.add_argument("--no-fastpath", action="store_true", help="force the reference's two-probe order")
     ap.add_argument("--no-fingerprint", action="store_true", help="disable the 4-bit fingerprint filter")
     ap.add_argument("--no-early-exit", action="store_true", help="disable the early-exit MPHF walk (presence masks)")
+    ap.add_argument("--no-bucket-table", action="store_true", help="switch the verification table off (every probe through the MPHF records + key records)")
+    ap.add_argument("--bucket-lanes", type=int, default=0, choices=[0, 1, 2, 4, 8], help="lanes that share one bucket read (0: the library's default)")
     ap.add_argument("--gpu-builder", action="store_true", help="build the MPHF on the GPU (parallel peeling) instead of the host")
     ap.add_argument("--query-mix", action="store_true", help="Q_mix: 50 %% genome windows on a random strand + 50 %% random (seed 8)")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a, sys.argv[1:]))        # child processes; this one never touches the GPU
+    world_env = int(os.environ.get("WORLD_SIZE", 1))
+    if a.gpus != world_env:
+        log(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world_env}: the launcher's world size is what runs")
+    if a.workload == "auto":
+        a.workload = "lookup23" if world_env == 1 else "count23"
+        if world_env > 1 and a.scaling is None:
+            a.scaling = "strong"
+    if a.scaling is None:
+        a.scaling = "weak"
     # stdout carries exactly ONE JSON line (rank 0): libraries that print banners to fd 1 (RCCL does at init) go to stderr
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    if a.workload == "selftest":
+        return run_selftest(a, real_stdout)
 
     import torch
     from aindex_amd import dist as adist, engine, _lib
@@ -356,106 +614,52 @@ def main():
 
     if a.workload == "lookup23":
         ix, g, keys, counts, pf = build_index23(a.genome, rank, world, dev, cache, a.gpu_builder)
-        if a.no_fastpath:
-            ix.set_canonical_fastpath(False)
-        if a.no_fingerprint:
-            ix.set_fingerprint_filter(False)
-        if a.no_early_exit:
-            ix.set_early_exit(False)
-        if a.query_mix:
-            q = engine.synth_mix23_t(8, g, a.queries, first=rank * a.queries)
-        else:
-            q = engine.synth_kmers_t(7, a.queries, 23, dev, first=rank * a.queries)
-        res = torch.empty(a.queries, dtype=torch.int32, device=f"cuda:{dev}")
-        step = lambda: ix.tf_ascii_t(q, res)
-        wall, kern_ms, _ = timed_steps(step, a.steps, a.warmup, dev)
-        hits = int((res != 0).sum().item())
-        hf = hits / a.queries
-        probes = 1.0 if (ix.canonical_only and not a.no_fastpath) else 2.0 - hf   # misses probe both strands
-        # checker reads: every probe without the fingerprint filter; with it only hits + 1/16 of the failing probes
-        checker_reads = probes if a.no_fingerprint else hf + (probes - hf) / 16.0
-        # one MPHF evaluation E = 92 B, + 8 B per checker read, + 4 B tf per hit, + 27 B streamed per query
-        bytes_per_query = 27.0 + probes * 92.0 + checker_reads * 8.0 + 4.0 * hf          # full evaluations
-        achieved = bytes_per_query * a.queries / (kern_ms * 1e-3) / 1e9
-        value = world * a.queries * a.steps / wall
-        out.update({"metric": "kmer_lookups_per_sec_23mer_batch", "value": value, "unit": "lookups/s",
-                    "ms_per_step": wall / a.steps * 1e3, "dtype": "u64",
-                    "config": {"workload": "configs[2]: 23-mer emphf MPHF batch lookup, uniform-random 23-mer ASCII queries resident in HBM",
-                               "queries_per_step_per_gpu": a.queries, "index_keys": ix.n, "genome_bp": a.genome,
-                               "query_seed": 8 if a.query_mix else 7, "query_set": "Q_mix" if a.query_mix else "Q_rand", "hit_fraction": hits / a.queries, "probes_per_query": probes,
-                               "canonical_fastpath": bool(ix.canonical_only and not a.no_fastpath),
-                               "fingerprint_filter": not a.no_fingerprint, "parallelism": f"replica x{world}"},
-                    "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                                 "traffic": None, "kernel": "k_lookup23_ascii", "kernel_ms": kern_ms,
-                                 "algorithmic_bytes_per_query": bytes_per_query}})
-        # what the kernel actually touches (instrumented launch of the same kernel, same settings): MPHF records read,
-        # key records read and evaluations carried through to the rank, per query
-        li = ix.lines_ascii_t(q).to(torch.int64)
-        mphf_recs = float((li & 15).sum().item()) / a.queries
-        key_recs = float(((li >> 4) & 15).sum().item()) / a.queries
-        completed = float((li >> 8).sum().item()) / a.queries
-        del li
-        lines_per_query = mphf_recs + key_recs
-        # SURVEY 8(d) per-unit figures: 8 B per bit-pair word read, 8 B block rank + 60 B scan per completed evaluation,
-        # 8 B per checker read, 4 B tf per hit, 27 B streamed per query
-        bytes_per_query = 27.0 + 8.0 * mphf_recs + 68.0 * completed + 8.0 * key_recs + 4.0 * hf
-        achieved = bytes_per_query * a.queries / (kern_ms * 1e-3) / 1e9
-        # 128-byte lines moved per query: one per record read + the streamed query / result bytes
-        line_gbs = (lines_per_query + 27.0 / 128.0) * 128.0 * a.queries / (kern_ms * 1e-3) / 1e9
-        # the reference algorithm's bytes for the same queries (104 B forward hit, 204 B reverse hit, 200 B miss, + 27 B streamed)
-        ref_bytes = 27.0 + (200.0 * (1.0 - hf) + 154.0 * hf)
-        # roofline.achieved follows the contract: SURVEY 8(d)'s per-query figure (the reference algorithm's bytes for this hit mix:
-        # 227 B on Q_rand) x queries / kernel time. The kernel answers with FEWER bytes than that figure (early exit: 1.16 records
-        # instead of two full evaluations), so the fraction can exceed 1; what it really asks for is under `reads_issued`, the
-        # HBM-side line traffic under `traffic` (PMC) / `line_traffic_estimate`, the random-read yardstick under `random_read`.
-        ref_gbs = ref_bytes * a.queries / (kern_ms * 1e-3) / 1e9
-        out["roofline"].update({"achieved": ref_gbs, "frac": ref_gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_query": ref_bytes,
-                                "note": "SURVEY 8(d) bytes per query (reference algorithm) / kernel time; > peak because the early-exit evaluation "
-                                        "reads 1.16 records per absent query instead of two full MPHF evaluations — see reads_issued",
-                                "reads_issued": {"bytes_per_query": bytes_per_query, "GBps": achieved, "frac": achieved / HBM_PEAK_GBS,
-                                                 "note": "what this kernel actually requests, at SURVEY 8(d)'s per-access sizes"},
-                                "line_traffic_estimate": {"GBps": line_gbs, "frac_of_peak": line_gbs / HBM_PEAK_GBS,
-                                                          "note": "records read x 128-byte lines + streamed bytes, per second; the PMC figure is `traffic`"}})
-        out["config"].update({"mphf_records_read_per_query": mphf_recs, "key_records_read_per_query": key_recs,
-                              "completed_evaluations_per_query": completed, "records_read_per_query": lines_per_query})
-        out["config"]["early_exit"] = not a.no_early_exit
-        if not a.no_gather_probe:
-            # the north_star's own denominator: the measured random-read rate of this GPU (64 B per access)
-            peak_acc = gather_roofline(dev)
-            ach_acc = lines_per_query * a.queries / (kern_ms * 1e-3)
-            out["roofline"]["random_read"] = {"peak_accesses_per_s": peak_acc, "achieved_accesses_per_s": ach_acc, "frac": ach_acc / peak_acc,
-                                              "accesses_per_query": lines_per_query,
-                                              "note": "peak = k_gather, uniform-random 16-byte reads over a 4 GiB table in HBM (SURVEY 8d-ii); most of the "
-                                                      "lookup's accesses hit the 61 MB MPHF table in the Infinity Cache, hence frac can exceed 1"}
+        del keys, counts
+        apply_ab_switches(ix, a)
+        qset = "Q_mix" if a.query_mix else "Q_rand"
+        m = measure_lookup23(ix, g, qset, a.queries, rank, world, dev, a.steps, a.warmup, not a.no_gather_probe)
+        q, res = m.pop("_q"), m.pop("_res")
+        value = m["value"]
+        out.update({"metric": "kmer_lookups_per_sec_23mer_batch", "value": value, "unit": "lookups/s", "ms_per_step": m["ms_per_step"], "dtype": "u64",
+                    "config": {**m["config"], "genome_bp": a.genome, "parallelism": f"replica x{world}"},
+                    "roofline": m["roofline"]})
         # BASELINE.json.published is {}; the reference's README figure is kept for orientation only (hardware unstated,
         # measured through Python list[str] on an unshipped index), so vs_baseline stays null
         out["published_reference_rate"] = {"value": 2.3e6, "unit": "lookups/s", "source": "reference README.md:14,480,596 (BASELINE.md section 1)",
                                            "ratio": value / 2.3e6}
-        tr = load_pmc_traffic("lookup23")
-        if tr:
-            out["roofline"]["traffic"] = tr.get("bytes_per_launch")
-            out["roofline"]["traffic_source"] = tr.get("source")
+        if rank == 0 and world == 1 and not a.no_cpu_baseline:
+            s_ = min(a.cpu_sample, a.queries)
+            qs = q[: s_ * 23].cpu().numpy()
+            cb = cpu_baseline_lookup23(ix, pf, qs, res[:s_].cpu().numpy().view(np.uint32), os.path.join(cache, "cpu"))
+            if "index_load_s" in cb:
+                out["index_load_s"] = cb.pop("index_load_s")
+            out["cpu_baseline"] = cb.get("reference", cb["port_1t"])
+            out["cpu_baseline_extra"] = {k: v for k, v in cb.items()}
+            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        del q, res
         if not a.no_secondary:
-            # the other half of BASELINE.json's metric: reads/s counted, each rank its own reads, tf[] merged by one
-            # all-reduce (RCCL over xGMI at N > 1). Never allowed to take the headline number down with it.
             sec = {}
+            # the other query set of SURVEY 8(d): Q_mix (50 % hits) when the headline is Q_rand, and the other way round
             try:
-                reads = engine.synth_reads_t(41, g, a.reads23, 150, rc_half=True, n_rate_ppm=1000, first_read=rank * a.reads23)
-                tfh = torch.zeros(ix.n, dtype=torch.int32, device=f"cuda:{dev}")
-                def step23():
-                    tfh.zero_()
-                    ix.count23_fixed_t(reads, _lib.CANON_TRUE_RC, tfh)
-                    adist.all_reduce_sum_(tfh)
-                w23, k23, _ = timed_steps(step23, 3, 1, dev)
-                total = int(tfh.to(torch.int64).sum().item())
-                ar23, _, _ = timed_steps(lambda: adist.all_reduce_sum_(tfh), 3, 1, dev) if world > 1 else (0.0, 0.0, [])
-                sec["count23_fixed_mphf"] = {"metric": "reads_per_sec_23mer_count_fixed_mphf", "value": world * a.reads23 * 3 / w23, "unit": "reads/s",
-                                             "reads_per_step_per_gpu": a.reads23, "ms_per_step": w23 / 3 * 1e3, "allreduce_ms_of_it": ar23 / 3 * 1e3,
-                                             "windows_counted_all_ranks": total,
-                                             "collective": "all_reduce(sum) of int32 tf[n]" if world > 1 else "none (1 rank)"}
-                del reads, tfh
+                other = "Q_rand" if a.query_mix else "Q_mix"
+                m2 = measure_lookup23(ix, g, other, a.queries, rank, world, dev, max(3, a.steps // 4), 1, False)
+                m2.pop("_q"); m2.pop("_res")
+                sec["lookup23_" + other] = {"metric": "kmer_lookups_per_sec_23mer_batch", "value": m2["value"], "unit": "lookups/s", "ms_per_step": m2["ms_per_step"],
+                                            "config": m2["config"], "roofline": m2["roofline"]}
             except Exception as e:  # pragma: no cover
-                sec["count23_fixed_mphf"] = {"error": f"{type(e).__name__}: {e}"}
+                sec["lookup23_other_query_set"] = {"error": f"{type(e).__name__}: {e}"}
+            # the other half of BASELINE.json's metric: reads/s counted — config 4 at its full size (200 M reads; N ranks share them),
+            # tf[] merged by one all-reduce (RCCL over xGMI at N > 1). Never allowed to take the headline number down with it.
+            try:
+                r = measure_count23_strong(ix, g, rank, world, dev, a.total_reads, 3, 1)
+                r["roofline"] = count23_roofline(ix, r["windows_this_rank"], r["reads_this_rank"], r["kernel_ms_this_rank"])
+                tr = load_pmc_traffic("count23", reads_per_launch=r["reads_this_rank"])
+                if tr:
+                    r["roofline"]["traffic"] = tr.get("bytes_per_launch")
+                    r["roofline"]["traffic_source"] = tr.get("source")
+                sec["count23_strong"] = r
+            except Exception as e:  # pragma: no cover
+                sec["count23_strong"] = {"error": f"{type(e).__name__}: {e}"}
             # BASELINE configs[1]: 13-mer dense 4^13 table, 10 M reads per rank, u64 table merged by one all-reduce
             try:
                 from aindex_amd.engine import Index as _Index13
@@ -464,13 +668,10 @@ def main():
                 g13 = engine.synth_genome_t(13, 4_000_000, dev)
                 reads13 = engine.synth_reads_t(14, g13, a.reads13, 150, n_rate_ppm=1000, first_read=rank * a.reads13)
                 tf13 = torch.empty(4 ** 13, dtype=torch.int64, device=f"cuda:{dev}")
-                def step13():
-                    ix13.count13_t(reads13, tf13)
-                    adist.all_reduce_sum_(tf13)
-                w13, k13, _ = timed_steps(step13, 3, 1, dev)
+                w13, k13, _ = timed_steps(lambda: adist.count13_sharded_t(ix13, reads13, tf13), 3, 1, dev)
                 total13 = int(tf13.sum().item())
                 ar13, _, _ = timed_steps(lambda: adist.all_reduce_sum_(tf13), 3, 1, dev) if world > 1 else (0.0, 0.0, [])
-                sec["count13_dense"] = {"metric": "reads_per_sec_13mer_count", "value": world * a.reads13 * 3 / w13, "unit": "reads/s",
+                sec["count13_dense"] = {"metric": "reads_per_sec_13mer_count", "value": world * a.reads13 * 3 / w13, "unit": "reads/s", "scaling": "weak",
                                         "reads_per_step_per_gpu": a.reads13, "ms_per_step": w13 / 3 * 1e3, "allreduce_ms_of_it": ar13 / 3 * 1e3,
                                         "windows_counted_all_ranks": total13,
                                         "collective": "all_reduce(sum) of int64 tf[4^13]" if world > 1 else "none (1 rank)"}
@@ -479,15 +680,6 @@ def main():
             except Exception as e:  # pragma: no cover
                 sec["count13_dense"] = {"error": f"{type(e).__name__}: {e}"}
             out["secondary"] = sec
-        if rank == 0 and world == 1 and not a.no_cpu_baseline:
-            s = min(a.cpu_sample, a.queries)
-            qs = q[: s * 23].cpu().numpy()
-            cb = cpu_baseline_lookup23(ix, pf, qs, res[:s].cpu().numpy().view(np.uint32), os.path.join(cache, "cpu"))
-            if "index_load_s" in cb:
-                out["index_load_s"] = cb.pop("index_load_s")
-            out["cpu_baseline"] = cb.get("reference", cb["port_1t"])
-            out["cpu_baseline_extra"] = {k: v for k, v in cb.items()}
-            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
 
     elif a.workload == "lookup13":
         from aindex_amd.engine import Index
@@ -538,60 +730,59 @@ def main():
             out["roofline"]["traffic"] = tr.get("bytes_per_launch")
             out["roofline"]["traffic_source"] = tr.get("source")
 
+    elif a.workload == "count23" and a.scaling == "strong":
+        ix, g, keys, counts, pf = build_index23(a.genome, rank, world, dev, cache)
+        del keys, counts
+        apply_ab_switches(ix, a)
+        r = measure_count23_strong(ix, g, rank, world, dev, a.total_reads, a.steps, a.warmup)
+        out.update({"metric": r["metric"], "value": r["value"], "unit": r["unit"], "scaling": "strong", "ms_per_step": r["ms_per_step"], "dtype": "u64",
+                    "config": {"workload": f"configs[3]: 23-mer counting, {a.total_reads} synthetic 150 bp reads (seed 41) in {world} contiguous read ranges, "
+                                           "histogram against the fixed MPHF index + all-reduce(sum) of tf[]",
+                               "total_reads": a.total_reads, "reads_this_rank": r["reads_this_rank"], "index_keys": ix.n, "genome_bp": a.genome,
+                               "parallelism": f"reads sharded x{world}, index replicated", "backend": r["backend"], "collective": r["collective"],
+                               "collective_ranks": r["collective_ranks"], "one_device_rehearsal": r["one_device_rehearsal"]},
+                    "allreduce_ms": r["allreduce_ms"], "allreduce_bytes": r["allreduce_bytes"], "tf_digest": r["tf_digest"],
+                    "windows_counted_all_ranks": r["windows_counted_all_ranks"],
+                    "roofline": count23_roofline(ix, r["windows_this_rank"], r["reads_this_rank"], r["kernel_ms_this_rank"])})
+        tr = load_pmc_traffic("count23", reads_per_launch=r["reads_this_rank"])
+        if tr:
+            out["roofline"]["traffic"] = tr.get("bytes_per_launch")
+            out["roofline"]["traffic_source"] = tr.get("source")
+        if rank == 0 and not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline_count23(ix, g, pf, dev, cache)
+
     elif a.workload == "count23":
         ix, g, keys, counts, pf = build_index23(a.genome, rank, world, dev, cache)
+        apply_ab_switches(ix, a)
         reads = engine.synth_reads_t(41, g, a.reads, 150, rc_half=True, n_rate_ppm=1000, first_read=rank * a.reads)
         tf = torch.zeros(ix.n, dtype=torch.int32, device=f"cuda:{dev}")
-        def step():
-            tf.zero_()
-            ix.count23_fixed_t(reads, _lib.CANON_TRUE_RC, tf)
-            adist.all_reduce_sum_(tf)
-        wall, kern_ms, _ = timed_steps(step, a.steps, a.warmup, dev)
+        step = lambda: adist.count23_sharded_t(ix, reads, _lib.CANON_TRUE_RC, tf)
+        wall, _, _ = timed_steps(step, a.steps, a.warmup, dev)
+        digest = tf_checksum(tf)
+        _, kern_ms, _ = timed_steps(lambda: ix.count23_fixed_t(reads, _lib.CANON_TRUE_RC, tf), 3, 0, dev)     # the kernel alone
         windows = a.reads * (150 - 22)
-        achieved = (a.reads * 151 + windows * (154.0 + 8.0)) / (kern_ms * 1e-3) / 1e9     # input + mean 154 B per hit (50/50 strands) + 8 B counter RMW
-        cb23 = None
-        if rank == 0 and world == 1 and not a.no_cpu_baseline:
-            # the reference has no tool for this composition (kmer_counter -> compute_index would re-derive the key set); the CPU
-            # path timed beside it is the C restatement of the same histogram (forward-then-rc MPHF probes per window), 1 thread
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            import oracle_lib as O
-            tmpd = os.path.join(cache, "cpu23c")
-            os.makedirs(tmpd, exist_ok=True)
-            prefix = os.path.join(tmpd, "c23")
-            open(prefix + ".pf", "wb").write(pf)
-            ix.tf_array().tofile(prefix + ".tf.bin")
-            ix.checker_array().tofile(prefix + ".kmers.bin")
-            orc = O.OracleIndex23.from_prefix(prefix)
-            ns = min(a.reads, 100_000)
-            sample = reads[: ns * 151]
-            gpu_s = torch.zeros(ix.n, dtype=torch.int32, device=f"cuda:{dev}")
-            ix.count23_fixed_t(sample, _lib.CANON_TRUE_RC, gpu_s)
-            t0 = time.perf_counter(); want = orc.count23_fixed(sample.cpu().numpy().tobytes(), False, 2); dt = time.perf_counter() - t0
-            assert np.array_equal(want, gpu_s.cpu().numpy().view(np.uint32)), "CPU port and GPU disagree on the sample"
-            cb23 = {"value": ns / dt, "unit": "reads/s", "cores": 1, "kind": "port", "sample": f"first {ns} reads of the batch"}
-            del orc
-            for f in (".pf", ".tf.bin", ".kmers.bin"):
-                os.remove(prefix + f)
+        cb23 = cpu_baseline_count23(ix, g, pf, dev, cache) if (rank == 0 and world == 1 and not a.no_cpu_baseline) else None
         out.update({**({"cpu_baseline": cb23} if cb23 else {}),
                     "metric": "reads_per_sec_23mer_count_fixed_mphf", "value": world * a.reads * a.steps / wall, "unit": "reads/s",
                     "ms_per_step": wall / a.steps * 1e3, "dtype": "u64",
-                    "config": {"workload": "configs[3]: 23-mer histogram against a fixed MPHF, 150 bp reads, + all-reduce(sum) of tf[]",
+                    "config": {"workload": "configs[3]-shaped: 23-mer histogram against a fixed MPHF, 150 bp reads, + all-reduce(sum) of tf[]; per-rank reads fixed (weak)",
                                "reads_per_step_per_gpu": a.reads, "index_keys": ix.n},
-                    "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                                 "traffic": None, "kernel": "k_count23_fixed (+all-reduce)", "kernel_ms": kern_ms}})
+                    "tf_digest": digest,
+                    "roofline": count23_roofline(ix, windows, a.reads, kern_ms)})
+        tr = load_pmc_traffic("count23", reads_per_launch=a.reads)
+        if tr:
+            out["roofline"]["traffic"] = tr.get("bytes_per_launch")
+            out["roofline"]["traffic_source"] = tr.get("source")
         if not a.no_gather_probe:
             peak_acc = gather_roofline(dev)
-            acc = 4.0                                                # three MPHF records + the key record per window (+ one atomic, not counted)
+            acc = out["roofline"]["lines_per_window"]
             ach = windows * acc / (kern_ms * 1e-3)
             out["roofline"]["random_read"] = {"peak_accesses_per_s": peak_acc, "achieved_accesses_per_s": ach, "frac": ach / peak_acc, "accesses_per_window": acc,
                                               "note": "peak = k_gather over a 4 GiB table; every window also issues one scattered atomic"}
 
     elif a.workload == "coverage23":
         ix, g, keys, counts, pf = build_index23(a.genome, rank, world, dev, cache)
-        if a.no_early_exit:
-            ix.set_early_exit(False)
-        if a.no_fingerprint:
-            ix.set_fingerprint_filter(False)
+        apply_ab_switches(ix, a)
         L = a.seq_len
         seqs = engine.synth_reads_t(51, g, a.seqs, L, rc_half=True, n_rate_ppm=1000, first_read=rank * a.seqs)   # records of L bases + '\n'
         offs = torch.arange(0, (a.seqs + 1) * (L + 1), L + 1, dtype=torch.int64, device=f"cuda:{dev}")
@@ -670,6 +861,7 @@ def main():
     elif a.workload == "positions23":
         from aindex_amd._lib import lib, check, vp
         ix, g, keys, counts, pf = build_index23(a.genome, rank, world, dev, cache)
+        apply_ab_switches(ix, a)
         reads_t = engine.synth_reads_t(41, g, a.reads, 150, rc_half=True, n_rate_ppm=1000)
         res = {}
         step = lambda: res.__setitem__("o", ix.positions_fill_t(reads_t))

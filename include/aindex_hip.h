@@ -57,6 +57,10 @@ typedef struct {
     uint64_t bitpairs;        /* 3 * hash_domain                                               */
     uint64_t device_bytes;    /* HBM held by this handle                                       */
     uint32_t canonical_only;  /* 1 if every stored 23-mer code <= its reverse complement       */
+    uint32_t bucket_table;    /* 1 if the verification table is built and switched on          */
+    uint64_t buckets;         /* its 128-byte buckets (0: not built)                           */
+    uint64_t bucket_unfiled_keys; /* keys beyond the eighth of their bucket (MPHF path)        */
+    uint32_t bucket_lanes;    /* lanes that share one bucket read (8, 4, 2 or 1)               */
     uint32_t reserved;
 } aix_info_t;
 
@@ -99,6 +103,12 @@ int aix_index_set_canonical_fastpath(aix_index_t* h, int enabled);
 int aix_index_set_fingerprint_filter(aix_index_t* h, int enabled);
 /* switch the early-exit MPHF walk (presence masks: an absent key usually costs one record read) off/on */
 int aix_index_set_early_exit(aix_index_t* h, int enabled);
+/* Verification table of a 23-mer handle (built at open unless AIX_BUCKET_TABLE=0): one 128-byte line per probe holding
+ * {code, tf, slot} of the keys filed under it, compared in-line — the hit of get_tf_value_23mer / get_kid_by_kmer
+ * (python_wrapper.cpp:610-627, hash.hpp:700-716) and of lu_compressed_worker's probe (hash.cpp:993-1054) in ONE read instead of
+ * three MPHF records + a key record; answers are identical with it on or off (A/B measurements, tests).
+ * lanes: how many lanes share one bucket read (8, 4, 2, 1; 0 = keep). */
+int aix_index_set_bucket_table(aix_index_t* h, int enabled, int lanes);
 /* replace the tf table of a 13-mer handle (u64[4^13], mphf order, HOST pointer) */
 int aix_index_set_tf_13(aix_index_t* h, const uint64_t* tf);
 /* copy tf out (HOST pointer): 23 -> u32[n]; 13 -> u64[4^13] in mphf order

@@ -34,6 +34,35 @@ def test_two_rank_gloo_counting_and_queries():
     assert r.returncode == 0 and "DIST_OK" in out, out[-3000:]
 
 
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus N` outside a torchrun environment launches the N ranks itself (child processes, rendezvous on
+    127.0.0.1), hands their ONE JSON line on with n_gpus = N and leaves with their status. The GPU-free `selftest` workload
+    exercises exactly that plumbing here; on the GPU box the same path runs the counting workload (scripts/gpu_dist_rehearsal.sh)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    for n in (2, 3):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--workload", "selftest", "--steps", "4", "--warmup", "1"],
+                           env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert r.returncode == 0, r.stderr.decode(errors="replace")[-3000:]
+        lines = r.stdout.decode().strip().splitlines()
+        assert len(lines) == 1, lines
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == n and d["value"] == n and d["steps"] == 4 and d["warmup"] == 1
+    # a rank that dies fails the launch: non-zero status, no JSON line
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "selftest"],
+                       env=dict(env, AIX_SELFTEST_FAIL_RANK="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode != 0 and r.stdout.decode().strip() == ""
+
+
+def test_device_tensor_sharded_counters_exist():
+    """No rank of the counting path uploads from host memory: the device-tensor entry points of the N > 1 path."""
+    import inspect
+    for name in ("count23_sharded_t", "count13_sharded_t"):
+        fn = getattr(adist, name)
+        src = inspect.getsource(fn)
+        assert "all_reduce_sum_" in src and "frombuffer" not in src and ".to(" not in src
+
+
 def test_exchange_merge_single_process_and_owner_hash():
     """Without a process group the exchange is the local merge alone; the owner hash is the splitmix64 finaliser (big-int check)."""
     import torch

@@ -64,9 +64,10 @@ def test_fuzz_queries_counts_positions(seed, tmp_path):
         qb = [bytes(x) for x in q[:400]]
         for fast in (True, False):
             for ee in (True, False):
-                ix.set_canonical_fastpath(fast); ix.set_early_exit(ee)
-                assert np.array_equal(ix.tf_ascii(q), want_tf), (seed, fast, ee)
-        ix.set_canonical_fastpath(True); ix.set_early_exit(True)
+                for bk, lanes in ((True, 8), (True, 1 << (seed % 3)), (False, 0)):     # verification table on (two lane widths) / off
+                    ix.set_canonical_fastpath(fast); ix.set_early_exit(ee); ix.set_bucket_table(bk, lanes)
+                    assert np.array_equal(ix.tf_ascii(q), want_tf), (seed, fast, ee, bk, lanes)
+        ix.set_canonical_fastpath(True); ix.set_early_exit(True); ix.set_bucket_table(seed % 2 == 0, 8)
         assert ix.total_ascii(q[:400]).tolist() == [orc.total(b) for b in qb]
         f, r = ix.both_ascii(q[:400])
         assert [(int(a), int(b)) for a, b in zip(f, r)] == [orc.both(b) for b in qb]
@@ -246,9 +247,10 @@ def test_fuzz_corrupt_index_files(seed, tmp_path):
         for fast in (True, False):
             for fp in (True, False):
                 for ee in (True, False):
-                    ix.set_canonical_fastpath(fast); ix.set_fingerprint_filter(fp); ix.set_early_exit(ee)
-                    assert np.array_equal(ix.tf_ascii(q), want), (seed, fast, fp, ee)
-        ix.set_canonical_fastpath(True); ix.set_fingerprint_filter(True); ix.set_early_exit(True)
+                    for bk in (True, False):
+                        ix.set_canonical_fastpath(fast); ix.set_fingerprint_filter(fp); ix.set_early_exit(ee); ix.set_bucket_table(bk, 8 >> (seed % 4))
+                        assert np.array_equal(ix.tf_ascii(q), want), (seed, fast, fp, ee, bk)
+        ix.set_canonical_fastpath(True); ix.set_fingerprint_filter(True); ix.set_early_exit(True); ix.set_bucket_table(seed % 2 == 1, 8)
         kid, strand = ix.kid_strand_ascii(q[:300])
         assert strand.tolist() == [orc.strand(b) for b in qb] and kid.tolist() == [orc.kid(b) for b in qb]
         assert ix.total_ascii(q[:300]).tolist() == [orc.total(b) for b in qb]

@@ -1074,9 +1074,10 @@ def test_early_exit_walk_on_off(canon_case, ix23, q23):
     for fast in (True, False):
         for fp in (True, False):
             for ee in (True, False):
-                ix.set_canonical_fastpath(fast); ix.set_fingerprint_filter(fp); ix.set_early_exit(ee)
-                assert np.array_equal(ix.tf_ascii(q), want), (fast, fp, ee)
-    ix.set_canonical_fastpath(True); ix.set_fingerprint_filter(True); ix.set_early_exit(True)
+                for bk in (True, False):
+                    ix.set_canonical_fastpath(fast); ix.set_fingerprint_filter(fp); ix.set_early_exit(ee); ix.set_bucket_table(bk)
+                    assert np.array_equal(ix.tf_ascii(q), want), (fast, fp, ee, bk)
+    ix.set_canonical_fastpath(True); ix.set_fingerprint_filter(True); ix.set_early_exit(True); ix.set_bucket_table(False)
     kid, strand = ix.kid_strand_ascii(q[:5000])
     assert strand.tolist() == [orc.strand(bytes(s)) for s in q[:5000]]
     qs = flat(q23["queries"])
@@ -1088,7 +1089,63 @@ def test_early_exit_walk_on_off(canon_case, ix23, q23):
     import torch
     from aindex_amd import engine
     li = ix.lines_ascii_t(engine.synth_kmers_t(7, 200_000, 23)).cpu().numpy()
-    assert 1.0 <= float((li & 15).mean()) < 2.0          # absent keys stop after ~1.35 records on average
+    assert 1.0 <= float((li & 15).mean()) < 2.0          # MPHF path: absent keys stop after ~1.35 records on average
+    ix.set_bucket_table(True)
+    li = ix.lines_ascii_t(engine.synth_kmers_t(7, 200_000, 23)).cpu().numpy()
+    assert float((li >> 16).mean()) == 1.0 and float((li & 15).mean()) < 0.2   # table on: one bucket line; the MPHF only behind an overflowed bucket
+
+
+def test_bucket_table_every_consumer_on_off_and_overflowing(canon_case, small23_prefix, monkeypatch):
+    """Verification table (one 128-byte line per probe): every consumer — tf / total / both / kid+strand / 2-bit codes /
+    coverage / count23 (three canonical modes) / positions fill — gives the answers of the MPHF path and of the oracle, for
+    every lane width, on the canonical synthetic index, on the reference-built golden index (non-canonical keys: two probes)
+    and on tables loaded so heavily (AIX_BUCKET_LOAD=8: ~40 % of the buckets overflow) that the fall-back runs all the time."""
+    orc, g = canon_case["orc"], canon_case["genome"]
+    prefix = canon_case["prefix"]
+    q = mixed_queries(g, 120_000, 77)
+    asc = synth.genome_ascii(23, 300_000)
+    reads = synth.reads_plain(41, asc, 2500, 150, rc_fraction_half=True, n_rate_ppm=1000).tobytes()
+    noisy = bytes(asc[5000:9000]).lower() + b"\n" + bytes(asc[100:400]).replace(b"C", b"R", 2) + b"~" + bytes(asc[900:1300]) + b"\n" + reads[:40_000]
+    seqs = [bytes(asc[1000:9000]), bytes(asc[20000:20030]), b"ACGT", b"", bytes(asc[9000:12000]).lower(), bytes(asc[40000:41000]).replace(b"A", b"N", 3)]
+    codes = synth.encode_kmers(synth.decode_kmers(synth.rolling_codes(g[:40_000], 23), 23))
+
+    def answers(ix):
+        kid, strand = ix.kid_strand_ascii(q)
+        f, r = ix.both_ascii(q[:20_000])
+        ind, pos = ix.positions_fill(noisy)
+        return {"tf": ix.tf_ascii(q), "total": ix.total_ascii(q[:20_000]), "fwd": f, "rc": r, "kid": kid, "strand": strand, "codes": ix.tf_codes(codes),
+                "cov": np.concatenate(ix.coverage(seqs, 0)), "c0": ix.count23_fixed(noisy, _lib.FMT_PLAIN, 0), "c1": ix.count23_fixed(noisy, _lib.FMT_PLAIN, 1),
+                "c2": ix.count23_fixed(reads, _lib.FMT_PLAIN, 2), "ind": ind, "pos": pos}
+
+    for load in (None, "8", "0.5"):
+        if load is None:
+            monkeypatch.delenv("AIX_BUCKET_LOAD", raising=False)
+        else:
+            monkeypatch.setenv("AIX_BUCKET_LOAD", load)
+        for pre, o in ((prefix, orc), (small23_prefix, None)):
+            with Index.open_23(pre + ".pf", pre + ".tf.bin", pre + ".kmers.bin") as ix:
+                info = ix.info
+                assert info["bucket_table"] == 1 and info["buckets"] >= 1
+                if load == "8" and pre == prefix:
+                    assert info["bucket_unfiled_keys"] > ix.n // 20          # the fall-back really is exercised
+                ix.set_bucket_table(False)
+                base = answers(ix)
+                if o is not None:
+                    assert np.array_equal(base["tf"], o.tf_batch(q, threads=8))
+                    assert np.array_equal(base["c2"], o.count23_fixed(reads, False, 2))
+                    oind, opos = o.positions(noisy)
+                    assert np.array_equal(base["ind"], oind) and np.array_equal(base["pos"], opos)
+                for lanes in (8, 4, 2, 1):
+                    ix.set_bucket_table(True, lanes)
+                    assert ix.info["bucket_lanes"] == lanes
+                    got = answers(ix)
+                    for k, v in base.items():
+                        assert np.array_equal(got[k], v), (load, pre, lanes, k)
+    monkeypatch.setenv("AIX_BUCKET_TABLE", "0")                              # not built at all: the MPHF path alone
+    with Index.open_23(prefix + ".pf", prefix + ".tf.bin", prefix + ".kmers.bin") as ix:
+        assert ix.info["bucket_table"] == 0 and ix.info["buckets"] == 0
+        ix.set_bucket_table(True, 8)                                         # nothing to switch on
+        assert np.array_equal(ix.tf_ascii(q), orc.tf_batch(q, threads=8))
 
 
 # ------------------------------------------------------------------------------------------------
