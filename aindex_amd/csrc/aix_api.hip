@@ -72,6 +72,9 @@ struct aix_index {
     uint32_t bk_lpp = 8;                       // lanes that share one bucket read
     uint64_t bk_unfiled = 0;                   // keys beyond the eighth of their bucket (answered through the MPHF)
     bool bk_enabled = true;
+    uint64_t* bloom = nullptr;                 // absence filter in front of the table (lookups / coverage)
+    uint32_t nbloom = 0;
+    bool bloom_enabled = true;
     uint64_t* tf13_mphf = nullptr;
     uint64_t* tf13_code = nullptr;
     uint32_t* perm13 = nullptr;
@@ -114,6 +117,8 @@ struct aix_index {
         d.bk = (bk && bk_enabled) ? bk : nullptr;
         d.nb = nb;
         d.bk_lpp = bk_lpp;
+        d.bloom = (d.bk && bloom && bloom_enabled) ? bloom : nullptr;
+        d.nbloom = nbloom;
         return d;
     }
 };
@@ -242,6 +247,7 @@ static void destroy(aix_index* h) {
     if (h->ee) (void)hipFree(h->ee);
     if (h->keys) (void)hipFree(h->keys);
     if (h->bk) (void)hipFree(h->bk);
+    if (h->bloom) (void)hipFree(h->bloom);
     if (h->tf13_mphf) (void)hipFree(h->tf13_mphf);
     if (h->tf13_code) (void)hipFree(h->tf13_code);
     if (h->perm13) (void)hipFree(h->perm13);
@@ -273,7 +279,19 @@ static int build_bucket_table(aix_index* h, hipStream_t s) {
     h->nb = (uint32_t)nb;
     h->device_bytes += bytes;
     HIPCHK(hipMemsetAsync(fill.p, 0, 4 * nb, s));
-    HIPCHK(launch_build_buckets(h->dev().m, h->keys, h->n, h->bk, h->nb, (uint32_t*)fill.p, s));
+    // absence filter: AIX_BLOOM_BITS bits per key (default 16: 2 B of Infinity-Cache-resident filter per key, < 1 % of the absent
+    // keys pass; 0 = no filter)
+    double bloom_bits = 16.0;
+    if (const char* e = getenv("AIX_BLOOM_BITS")) { const double v = atof(e); if (v == 0.0 || (v >= 4.0 && v <= 64.0)) bloom_bits = v; }
+    if (bloom_bits > 0) {
+        uint64_t nw = (uint64_t)((double)h->n * bloom_bits / 64.0) + 1;
+        if (nw > 0xFFFFFFF0ull) nw = 0xFFFFFFF0ull;
+        HIPCHK(hipMalloc((void**)&h->bloom, 8 * nw));
+        h->nbloom = (uint32_t)nw;
+        h->device_bytes += 8 * nw;
+        HIPCHK(hipMemsetAsync(h->bloom, 0, 8 * nw, s));
+    }
+    HIPCHK(launch_build_buckets(h->dev().m, h->keys, h->n, h->bk, h->nb, (uint32_t*)fill.p, h->bloom, h->nbloom, s));
     // keys left to the MPHF path: sum over buckets of max(fill - 8, 0) (host side: once per open, nb words)
     std::vector<uint32_t> f;
     try { f.resize(nb); } catch (const std::bad_alloc&) { return AIX_ERR_NOMEM; }
@@ -520,6 +538,7 @@ extern "C" int aix_index_info(const aix_index_t* h, aix_info_t* info) {
     info->bucket_lanes = h->bk_lpp;
     info->buckets = h->bk ? h->nb : 0;
     info->bucket_unfiled_keys = h->bk_unfiled;
+    info->absence_filter_words = (h->bk && h->bk_enabled && h->bloom && h->bloom_enabled) ? h->nbloom : 0;
     return AIX_OK;
 }
 
@@ -538,6 +557,12 @@ extern "C" int aix_index_set_fingerprint_filter(aix_index_t* h, int enabled) {
 extern "C" int aix_index_set_early_exit(aix_index_t* h, int enabled) {
     if (!h) return AIX_ERR_ARG;
     h->early_exit = enabled != 0;
+    return AIX_OK;
+}
+
+extern "C" int aix_index_set_absence_filter(aix_index_t* h, int enabled) {
+    if (!h) return AIX_ERR_ARG;
+    h->bloom_enabled = enabled != 0;
     return AIX_OK;
 }
 
@@ -680,6 +705,8 @@ extern "C" int aix_coverage_batch_dev(aix_index_t* h, const char* d_seqs, const 
     return AIX_OK;
 }
 
+static int ensure_count_workspace(aix_index* h, uint64_t need, hipStream_t s);
+
 extern "C" int aix_count13_dev(aix_index_t* h, const char* d_plain, uint64_t len, uint64_t* d_tf_out, void* stream) {
     if (!h || !d_tf_out || (len && !d_plain)) return AIX_ERR_ARG;
     if (h->k != 13) return AIX_ERR_MODE;
@@ -711,13 +738,7 @@ extern "C" int aix_count13_dev(aix_index_t* h, const char* d_plain, uint64_t len
         if (const char* e = getenv("AIX_COUNT13_PIECE")) { const uint64_t v = strtoull(e, nullptr, 10); if (v >= 1 && v <= (1ull << 31)) piece = v; }
         const uint64_t nwin = len >= 13 ? len - 12 : 0;
         const uint64_t need = count13_workspace_bytes(std::min(nwin, piece) + 12);
-        if (need > h->work13_bytes) {
-            HIPCHK(hipStreamSynchronize(s));
-            if (h->work13) { (void)hipFree(h->work13); h->device_bytes -= h->work13_bytes; h->work13 = nullptr; h->work13_bytes = 0; }
-            HIPCHK(hipMalloc(&h->work13, need));
-            h->work13_bytes = need;
-            h->device_bytes += need;
-        }
+        { const int stw = ensure_count_workspace(h, need, s); if (stw) return stw; }
         HIPCHK(hipMemsetAsync(d_tf_out, 0, 8 * AIX_TOTAL_13MERS, s));
         HIPCHK(hipMemsetAsync(h->work13, 0, 4, s));                               // the error word of the workspace
         for (uint64_t first = 0; first < nwin; first += piece) {
@@ -737,12 +758,63 @@ extern "C" int aix_count13_dev(aix_index_t* h, const char* d_plain, uint64_t len
     return AIX_OK;
 }
 
+// grow-only per-handle workspace of the counting paths (13-mer partitions; 23-mer slot stream + partitions). Calls are ordered
+// behind one another even when they come in on different streams (the mutex only orders the enqueueing).
+static int ensure_count_workspace(aix_index* h, uint64_t need, hipStream_t s) {
+    if (need <= h->work13_bytes) return AIX_OK;
+    HIPCHK(hipStreamSynchronize(s));
+    if (h->work13) { (void)hipFree(h->work13); h->device_bytes -= h->work13_bytes; h->work13 = nullptr; h->work13_bytes = 0; }
+    HIPCHK(hipMalloc(&h->work13, need));
+    h->work13_bytes = need;
+    h->device_bytes += need;
+    return AIX_OK;
+}
+
 extern "C" int aix_count23_fixed_dev(aix_index_t* h, const char* d_plain, uint64_t len, int canon_mode, uint32_t* d_tf_out, void* stream) {
     if (!h || !d_tf_out || (len && !d_plain)) return AIX_ERR_ARG;
     if (h->k != 23) return AIX_ERR_MODE;
     if (canon_mode < 0 || canon_mode > 2) return AIX_ERR_ARG;
     DevGuard g(h->device);
-    HIPCHK(launch_count23_fixed(h->dev(), (const uint8_t*)d_plain, len, canon_mode, d_tf_out, (hipStream_t)stream));
+    hipStream_t s = (hipStream_t)stream;
+    const uint64_t nwin = len >= 23 ? len - 22 : 0;
+    if (nwin == 0 || h->n == 0) return AIX_OK;
+    // Two back ends, same result. (a) one memory-side atomic per found window: ~23 G scattered atomics/s on MI355X, which bounds the
+    // kernel once a probe costs a single line. (b) the slots are streamed out (4 B per window) and added into tf[] by the
+    // chunked-partition + LDS histogram of the 13-mer counter: no global atomics at all. (b) needs slots < 2^26 (2048 partitions of
+    // 32 768 bins) and pays a fixed cost, so short buffers keep (a). AIX_COUNT23_ATOMICS=1 forces (a); AIX_COUNT23_HIST_MIN moves
+    // the threshold (tests run (b) on small inputs).
+    uint64_t hist_min = 1ull << 22;
+    if (const char* e = getenv("AIX_COUNT23_HIST_MIN")) hist_min = strtoull(e, nullptr, 10);
+    const bool use_hist = h->n <= (1ull << 26) && nwin >= hist_min && getenv("AIX_COUNT23_ATOMICS") == nullptr;
+    if (!use_hist) {
+        HIPCHK(launch_count23_fixed(h->dev(), (const uint8_t*)d_plain, len, canon_mode, d_tf_out, s));
+        return AIX_OK;
+    }
+    std::lock_guard<std::mutex> lk(h->count_mutex);
+    if (h->work13_done) HIPCHK(hipStreamWaitEvent(s, h->work13_done, 0));
+    else HIPCHK(hipEventCreateWithFlags(&h->work13_done, hipEventDisableTiming));
+    struct RecordOnExit {
+        hipEvent_t ev; hipStream_t st;
+        ~RecordOnExit() { (void)hipEventRecord(ev, st); }
+    } record_on_exit{h->work13_done, s};
+    uint64_t piece = 1ull << 28;                                               // windows per pass: 1 GiB of slots + ~1 GiB of partitions
+    if (const char* e = getenv("AIX_COUNT23_PIECE")) { const uint64_t v = strtoull(e, nullptr, 10); if (v >= 1 && v <= (1ull << 31)) piece = v; }
+    const uint64_t pw = std::min(piece, nwin);
+    const uint64_t part_bytes = (count13_workspace_bytes(pw + 12) + 255) / 256 * 256;
+    int st = ensure_count_workspace(h, part_bytes + 4 * pw, s);
+    if (st) return st;
+    uint32_t* slots = (uint32_t*)((uint8_t*)h->work13 + part_bytes);
+    HIPCHK(hipMemsetAsync(h->work13, 0, 4, s));                               // the error word of the partition workspace
+    const IndexDev d = h->dev();
+    for (uint64_t first = 0; first < nwin; first += pw) {
+        const uint64_t w = std::min(pw, nwin - first);
+        HIPCHK(launch_probe23_slots(d, (const uint8_t*)d_plain + first, w + 22, canon_mode, slots, s));
+        HIPCHK(launch_histogram_slots(slots, w, h->work13, d_tf_out, h->n, s));
+    }
+    uint32_t dropped = 0;
+    HIPCHK(hipMemcpyAsync(&dropped, h->work13, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (dropped) { set_last_error("count23: chunk region exhausted (partition workspace undersized)"); return AIX_ERR_UNSUPPORTED; }
     return AIX_OK;
 }
 

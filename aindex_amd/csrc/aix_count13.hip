@@ -46,11 +46,15 @@ struct Run13 {
         else c = __funnelshift_r(w[2], w[1], sh);
         return c & 0x3FFFFFFu;
     }
+    template <int J>
+    __device__ __forceinline__ void get(uint32_t& c, uint32_t& ok) const { c = code<J>(); ok = (valid >> J) & 1u; }
 };
-template <int J, typename F>
-__device__ __forceinline__ void for_each_window13(const Run13& r, F&& f) {
+template <int J, typename RUN, typename F>
+__device__ __forceinline__ void for_each_window13(const RUN& r, F&& f) {
     if constexpr (J < C13_WPT) {
-        f(J, r.template code<J>(), (r.valid >> J) & 1u);
+        uint32_t code, ok;
+        r.template get<J>(code, ok);
+        f(J, code, ok);
         for_each_window13<J + 1>(r, f);
     }
 }
@@ -96,6 +100,34 @@ __device__ __forceinline__ Run13 encode_run13(const uint8_t* __restrict__ buf, u
     return r;
 }
 
+// What the split kernel sorts: 32 keys of at most 26 bits per lane and tile, with a validity bit each.
+struct Src13 {                                        // the 13-mer windows of a PLAIN reads buffer (count_kmers13)
+    const uint8_t* buf;
+    uint64_t len;
+    __device__ __forceinline__ Run13 load(uint64_t tile, int t) const { return encode_run13(buf, len, tile * C13_TILE + (uint64_t)t * C13_WPT); }
+};
+struct RunSlots {                                     // element j of this lane = p[j * 1024]: every load instruction of the workgroup reads 4 KiB of
+    const uint32_t* p;                                // consecutive slots. Nothing is kept in registers between the two passes of the tile sort
+    uint32_t limit;                                   // (32 more live registers spill): the second pass re-reads the 128 KiB tile through L2
+    template <int J>
+    __device__ __forceinline__ void get(uint32_t& c, uint32_t& ok) const {
+        const uint32_t v = (uint32_t)(J * C13_TB) < limit ? p[J * C13_TB] : 0xFFFFFFFFu;
+        c = v & 0x3FFFFFFu;
+        ok = v != 0xFFFFFFFFu ? 1u : 0u;
+    }
+};
+struct SrcSlots {                                     // a stream of MPHF slots (< 2^26) in HBM, 0xFFFFFFFF = nothing to count (count23)
+    const uint32_t* slots;
+    uint64_t n;
+    __device__ __forceinline__ RunSlots load(uint64_t tile, int t) const {
+        const uint64_t base = tile * C13_TILE + (uint64_t)t;
+        RunSlots r;
+        r.p = slots + base;
+        r.limit = base < n ? (uint32_t)min((uint64_t)C13_TILE, n - base) : 0u;   // elements [0, limit) of p are inside the stream
+        return r;
+    }
+};
+
 // ---------------------------------------------------------------------------------------------
 // Chunked partitions: a workgroup's share of a partition is a list of 256-entry chunks, so nothing has to be sized
 // before the split (an earlier version ran a separate sizing pass — encode + 1.4e9 LDS atomics + a column scan, 1.2 ms per
@@ -111,7 +143,8 @@ static constexpr int C13_FILLBITS = 9;                // cursor = (chunk << 9) |
 // out with the same block scan that orders the tile (the per-partition chunk demand rides in the high half of the scan).
 // A chunk id at or past `region` cannot happen while chunk_region() is right; if it ever does, the write is dropped AND `err`
 // is raised, so the call fails with AIX_ERR_UNSUPPORTED instead of returning short counts.
-__global__ void __launch_bounds__(C13_TB) k_c13_split_chunked(const uint8_t* __restrict__ buf, uint64_t len, uint64_t ntiles, uint32_t region,
+template <class SRC>
+__global__ void __launch_bounds__(C13_TB) k_c13_split_chunked(const SRC src, uint64_t ntiles, uint32_t region,
                                                              uint16_t* __restrict__ dir_part, uint16_t* __restrict__ dir_cnt, uint16_t* __restrict__ parts,
                                                              uint32_t* __restrict__ err) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -132,7 +165,7 @@ __global__ void __launch_bounds__(C13_TB) k_c13_split_chunked(const uint8_t* __r
     __syncthreads();
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         uint32_t rank[C13_WPT / 2];                              // two 16-bit ranks per register
-        const Run13 run = encode_run13(buf, len, tile * C13_TILE + (uint64_t)t * C13_WPT);
+        const auto run = src.load(tile, t);
         const uint32_t dummy = C13_P + (t & (C13_DUMMY - 1));
         for_each_window13<0>(run, [&](int j, uint32_t code, uint32_t ok) {
             const uint32_t r = atomicAdd(&hist[ok ? code >> C13_BINBITS : dummy], 1u);
@@ -217,7 +250,8 @@ __global__ void __launch_bounds__(C13_TB) k_c13_split_chunked(const uint8_t* __r
 // v_readlane, eight 512-byte chunk loads in flight (64 KiB per CU), so no load depends on another one inside the loop.
 __global__ void __launch_bounds__(C13_TB) k_c13_hist_chunked(const uint16_t* __restrict__ parts, const uint16_t* __restrict__ spart /* sorted partition ids */,
                                                             const uint64_t* __restrict__ sdesc, uint32_t cap, unsigned long long* __restrict__ table,
-                                                            const uint32_t* __restrict__ perm, uint64_t* __restrict__ out_mphf, int accumulate) {
+                                                            const uint32_t* __restrict__ perm, uint64_t* __restrict__ out_mphf, int accumulate,
+                                                            uint32_t* __restrict__ out32 = nullptr, uint64_t n32 = 0) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ uint32_t range[2];
     uint32_t* h = (uint32_t*)smem;                              // [BINS]
@@ -258,7 +292,12 @@ __global__ void __launch_bounds__(C13_TB) k_c13_hist_chunked(const uint16_t* __r
         }
         __syncthreads();
         const uint64_t base = (uint64_t)p * C13_BINS;
-        if (perm) {
+        if (out32) {                                            // count23: bins are MPHF slots, tf_out[slot] += count (one writer per slot)
+            for (int i = threadIdx.x; i < C13_BINS; i += C13_TB) {
+                const uint32_t c = h[i];
+                if (c && base + i < n32) out32[base + i] += c;
+            }
+        } else if (perm) {
             for (int i = threadIdx.x; i < C13_BINS; i += C13_TB) {
                 const uint32_t c = h[i];
                 if (c) { const uint32_t slot = perm[base + i]; if (slot < 67108864u) out_mphf[slot] = accumulate ? out_mphf[slot] + c : (uint64_t)c; }
@@ -305,9 +344,9 @@ uint64_t count13_workspace_bytes(uint64_t len) {
     return 256 + 3 * align_up(2 * cap, 256) + align_up(8 * cap, 256) + align_up(dir_sort_temp_bytes((uint32_t)cap), 256) + 2 * cap * C13_CH + 256;
 }
 
-hipError_t launch_count13_partitioned(const uint8_t* buf, uint64_t len, void* workspace, unsigned long long* table, const uint32_t* perm,
-                                      uint64_t* out_mphf, int accumulate, hipStream_t s) {
-    const uint64_t nwin = len >= 13 ? len - 12 : 0;
+template <class SRC>
+static hipError_t partitioned_histogram(const SRC& src, uint64_t nwin, void* workspace, unsigned long long* table, const uint32_t* perm, uint64_t* out_mphf,
+                                        int accumulate, uint32_t* out32, uint64_t n32, hipStream_t s) {
     if (nwin > (1ull << 31)) return hipErrorInvalidValue;
     const uint32_t cap = chunk_capacity(nwin);
     uint8_t* w = (uint8_t*)workspace;
@@ -327,18 +366,31 @@ hipError_t launch_count13_partitioned(const uint8_t* buf, uint64_t len, void* wo
     {   // > 64 KiB of dynamic LDS needs the attribute; set per call (cheap, and correct for every device / thread)
         hipError_t e = hipFuncSetAttribute((const void*)k_c13_hist_chunked, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)k_c13_split_chunked, hipFuncAttributeMaxDynamicSharedMemorySize, (int)split_lds);
+        e = hipFuncSetAttribute((const void*)k_c13_split_chunked<SRC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)split_lds);
         if (e != hipSuccess) return e;
     }
     hipError_t e = hipMemsetD16Async((hipDeviceptr_t)dir_part, (unsigned short)C13_P, cap, s);     // "no partition": sorts behind every real one
     if (e == hipSuccess) e = hipMemsetD16Async((hipDeviceptr_t)dir_cnt, (unsigned short)C13_CH, cap, s);     // chunks are full unless the split says otherwise
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_c13_split_chunked, dim3(grid), dim3(C13_TB), split_lds, s, buf, len, ntiles, chunk_region(nwin), dir_part, dir_cnt, parts, err);
+    hipLaunchKernelGGL(k_c13_split_chunked<SRC>, dim3(grid), dim3(C13_TB), split_lds, s, src, ntiles, chunk_region(nwin), dir_part, dir_cnt, parts, err);
     auto vals = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), ChunkDesc{dir_cnt});
     e = rocprim::radix_sort_pairs(tmp, tmp_bytes, (const uint16_t*)dir_part, spart, vals, sdesc, (size_t)cap, 0u, 12u, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_c13_hist_chunked, dim3(C13_P), dim3(C13_TB), hist_lds, s, parts, spart, sdesc, cap, table, perm, out_mphf, accumulate);
+    hipLaunchKernelGGL(k_c13_hist_chunked, dim3(C13_P), dim3(C13_TB), hist_lds, s, parts, spart, sdesc, cap, table, perm, out_mphf, accumulate, out32, n32);
     return hipGetLastError();
+}
+
+hipError_t launch_count13_partitioned(const uint8_t* buf, uint64_t len, void* workspace, unsigned long long* table, const uint32_t* perm,
+                                      uint64_t* out_mphf, int accumulate, hipStream_t s) {
+    const uint64_t nwin = len >= 13 ? len - 12 : 0;
+    return partitioned_histogram(Src13{buf, len}, nwin, workspace, table, perm, out_mphf, accumulate, nullptr, 0, s);
+}
+
+// count23 back end: tf_out[slot] += occurrences of slot in d_slots[0, nslots) (0xFFFFFFFF entries are skipped); every slot < 2^26.
+// Same workspace layout as the 13-mer counter (count13_workspace_bytes(nslots + 12)).
+hipError_t launch_histogram_slots(const uint32_t* d_slots, uint64_t nslots, void* workspace, uint32_t* tf_out, uint64_t n, hipStream_t s) {
+    if (nslots == 0) return hipSuccess;
+    return partitioned_histogram(SrcSlots{d_slots, nslots}, nslots, workspace, nullptr, nullptr, nullptr, 1, tf_out, n, s);
 }
 
 }  // namespace aix

@@ -65,6 +65,15 @@ struct __attribute__((aligned(16))) BkEntry {
 #define AIX_BK_EMPTY_HI 0x3FFFFFFFu
 #define AIX_BK_NONE 0xFFFFFFFFu
 
+// Absence filter in front of the verification table (lookups and coverage, where most probes may be absent keys): a blocked
+// Bloom filter, one 64-bit word per probe, four bits per key, filled from the same keys as the table. It is small enough to
+// live in the Infinity Cache (16 bits per key by default), so an absent key is usually answered by ONE 8-byte cached read and
+// never reaches HBM; a filed key passes it by construction. Word and bits come from hash words the bucket choice does not use.
+__device__ __forceinline__ uint64_t bloom_mask(uint64_t c) {
+    return (1ull << (c & 63)) | (1ull << ((c >> 6) & 63)) | (1ull << ((c >> 12) & 63)) | (1ull << ((c >> 18) & 63));
+}
+__device__ __forceinline__ uint32_t bloom_word(uint64_t b, uint32_t nwords) { return (uint32_t)__umul64hi(b, (uint64_t)nwords); }
+
 // ---------------------------------------------------------------------------------------------
 // exact h % d for a launch-invariant d (Moeller-Granlund 2-by-1 division, 32-bit limbs).
 // gfx950 has no 64-bit integer divide; three of these replace the three `%` of mphf::lookup.
@@ -425,9 +434,16 @@ __device__ __forceinline__ BkRes bucket_probe_wave(const BkEntry* __restrict__ b
 #pragma unroll
     for (int r = 0; r < LPP; ++r) {
         bsrc[r] = LPP == 1 ? my_b : bperm(gbase + r, my_b);
-        const uint4* p = (const uint4*)(bk + (uint64_t)(bsrc[r] != AIX_BK_NONE ? bsrc[r] : 0u) * 8 + j * EPL);   // bucket 0 is always there
 #pragma unroll
-        for (int t = 0; t < EPL; ++t) e[r][t] = p[t];
+        for (int t = 0; t < EPL; ++t) e[r][t] = make_uint4(0xFFFFFFFFu, AIX_BK_EMPTY_HI, 0u, 0u);
+        // a round in which no group of the wave has a probe (most rounds, when the absence filter has answered nearly every
+        // lane) is skipped as a whole — a scalar branch; otherwise every lane loads (a group without a probe reads bucket 0,
+        // which is always there: cheaper than masking the loads lane by lane)
+        if (__ballot(bsrc[r] != AIX_BK_NONE) != 0ull) {
+            const uint4* p = (const uint4*)(bk + (uint64_t)(bsrc[r] != AIX_BK_NONE ? bsrc[r] : 0u) * 8 + j * EPL);
+#pragma unroll
+            for (int t = 0; t < EPL; ++t) e[r][t] = p[t];
+        }
     }
     BkRes res{0u, 0u, 0u, 0u};
 #pragma unroll

@@ -21,6 +21,8 @@ struct IndexDev {
     const BkEntry* bk;        // 23-mer: verification table (nb buckets of 8 entries), nullptr when not built / switched off
     uint32_t nb;
     uint32_t bk_lpp;          // lanes that share one bucket read (8, 4, 2 or 1); launch-time choice
+    const uint64_t* bloom;    // 23-mer: absence filter in front of the table (nbloom 64-bit words), nullptr when off
+    uint32_t nbloom;
 };
 
 enum LookupMode { MODE_TF = 0, MODE_HASH = 1, MODE_KIDSTRAND = 2, MODE_BOTH = 3, MODE_TOTAL = 4, MODE_LINES = 5 };
@@ -51,7 +53,8 @@ hipError_t launch_build_keyrecs(const uint64_t* checker, const uint32_t* tf, uin
 hipError_t launch_set_fingerprints(const MphfDev& m, BvRec* recs_rw, EeRec* ee_rw, const KeyRec* keys, uint64_t n, hipStream_t s);
 // verification table: bk (nb * 8 entries) is initialised and filled from the keys that sit in their own MPHF slot;
 // fill = nb zeroed u32 counters (scratch)
-hipError_t launch_build_buckets(const MphfDev& m, const KeyRec* keys, uint64_t n, BkEntry* bk, uint32_t nb, uint32_t* fill, hipStream_t s);
+hipError_t launch_build_buckets(const MphfDev& m, const KeyRec* keys, uint64_t n, BkEntry* bk, uint32_t nb, uint32_t* fill, uint64_t* bloom /* zeroed, nullable */,
+                                uint32_t nbloom, hipStream_t s);
 hipError_t launch_scatter23(const MphfDev& m, uint64_t n, uint64_t nslots, const uint8_t* keys_ascii /* or */, const uint64_t* codes, const uint32_t* counts,
                             uint64_t* checker, uint32_t* tf, uint32_t* occupied_bits, uint32_t* conflict, hipStream_t s);
 hipError_t launch_perm13(const MphfDev& m, uint32_t* perm /* [4^13]: code -> mphf index */, hipStream_t s);
@@ -64,6 +67,10 @@ uint64_t count13_workspace_bytes(uint64_t len);
 // perm/out_mphf set: counters are written straight into the (pre-zeroed) mphf-ordered output; else into table_code
 hipError_t launch_count13_partitioned(const uint8_t* buf, uint64_t len, void* workspace, unsigned long long* table_code, const uint32_t* perm,
                                       uint64_t* out_mphf, int accumulate, hipStream_t s);
+// count23 without global atomics: tf_out[slot] += occurrences of slot in the stream (slots < 2^26, 0xFFFFFFFF = skip)
+hipError_t launch_histogram_slots(const uint32_t* d_slots, uint64_t nslots, void* workspace /* count13_workspace_bytes(nslots + 12) */, uint32_t* tf_out,
+                                  uint64_t n, hipStream_t s);
+hipError_t launch_probe23_slots(const IndexDev& ix, const uint8_t* buf, uint64_t len, int canon_mode, uint32_t* slots /* [len - 22] */, hipStream_t s);
 hipError_t launch_scatter13_to_mphf(const uint32_t* perm, const unsigned long long* table_code, uint64_t* out_mphf, int add, hipStream_t s);
 hipError_t launch_perm13_check(const uint32_t* perm, uint32_t* bits /* 4^13 / 32 zeroed words */, uint32_t* bad /* zeroed */, hipStream_t s);
 hipError_t launch_count23_fixed(const IndexDev& ix, const uint8_t* buf, uint64_t len, int canon_mode, uint32_t* tf_out, hipStream_t s);

@@ -23,7 +23,7 @@ static inline unsigned grid_for(uint64_t work, unsigned per_block = kBlock) {
 struct Probe {
     uint64_t slot;
     uint32_t tf;
-    uint32_t lines;     // instrumentation for MODE_LINES: MPHF records read | 16 per key record read | 256 per completed evaluation | 65536 per bucket line
+    uint32_t lines;     // instrumentation for MODE_LINES: MPHF records read | 16 per key record read | 256 per completed evaluation | 4096 per filter word | 65536 per bucket line
     bool found;
 };
 // MPHF path: evaluate the MPHF on the hash (a, b, c) of the probed bytes, verify against the stored code.
@@ -74,18 +74,25 @@ __device__ __forceinline__ Probe probe23_hashed(const IndexDev& ix, uint64_t a, 
 // The probe of the batch kernels. EVERY lane of the wave calls it (want = false: this lane has nothing to probe); with the
 // verification table on, a probe whose hashed bytes are the ASCII of `code` (filters) is answered from its bucket line, all
 // others — and an unmatched probe of an overflowed bucket — by the MPHF path.
+// `absence`: consult the absence filter first (wave-uniform; the callers switch it per loop trip, see FilterGauge).
 template <int LPP>
-__device__ __forceinline__ Probe probe23_wave(const IndexDev& ix, bool want, uint64_t w0, uint64_t w1, uint64_t w2, uint64_t code, bool filters = true) {
+__device__ __forceinline__ Probe probe23_wave(const IndexDev& ix, bool want, uint64_t w0, uint64_t w1, uint64_t w2, uint64_t code, bool filters = true,
+                                              bool absence = true) {
     uint64_t a = 0, b = 0, c = 0;
     if (want) jenkins23(w0, w1, w2, ix.m.seed, a, b, c);
     Probe r;
     r.found = false; r.tf = 0; r.slot = 0; r.lines = 0;
     bool mphf = want;
     if (ix.bk) {
-        const bool use = want && filters;
+        bool use = want && filters;
+        if (ix.bloom && absence && use) {                       // absent from the filter = not a filed key; an unfiled key (overflow) is in it too
+            r.lines = 4096;
+            const uint64_t m = bloom_mask(c);
+            if ((ix.bloom[bloom_word(b, ix.nbloom)] & m) != m) { use = false; mphf = false; }
+        }
         const BkRes k = bucket_probe_wave<LPP>(ix.bk, ix.nb, use, a, code);
         if (use) {
-            r.lines = 65536;
+            r.lines += 65536;
             if (k.found) { r.found = true; r.tf = k.tf; r.slot = k.slot; }
             mphf = !k.found && k.overflow;
         }
@@ -97,6 +104,17 @@ __device__ __forceinline__ Probe probe23_wave(const IndexDev& ix, bool want, uin
     return r;
 }
 
+// The absence filter pays when most probes are absent keys (one cached 8-byte read instead of a 128-byte line from HBM) and
+// costs when most are present (one more read each). A wave decides trip by trip from what it has just seen: the filter is
+// consulted in the next trip iff fewer than a quarter of this trip's queries were found. The answers do not depend on it.
+struct FilterGauge {
+    bool on = true;
+    __device__ __forceinline__ void seen(bool active, bool found) {
+        const uint32_t a = (uint32_t)__popcll(__ballot(active)), f = (uint32_t)__popcll(__ballot(active && found));
+        if (a) on = 4u * f < a;
+    }
+};
+
 // Result of get_tf_value_23mer-style probing (python_wrapper.cpp:610-627): strand 0 absent, 1 fwd, 2 rc
 struct Q23 {
     uint64_t slot;
@@ -106,7 +124,7 @@ struct Q23 {
 };
 // wave-cooperative (all lanes call it; `active` = this lane holds a query)
 template <bool CANON, int LPP>
-__device__ __forceinline__ Q23 query23(const IndexDev& ix, bool active, uint64_t w0, uint64_t w1, uint64_t w2) {
+__device__ __forceinline__ Q23 query23(const IndexDev& ix, bool active, uint64_t w0, uint64_t w1, uint64_t w2, FilterGauge& fg) {
     const Enc23 e = encode23_words(w0, w1, w2);
     const uint64_t r = revcomp(e.code, 23);
     Q23 out;
@@ -117,7 +135,8 @@ __device__ __forceinline__ Q23 query23(const IndexDev& ix, bool active, uint64_t
         const bool fwd = e.code <= r;
         uint64_t x0 = w0, x1 = w1, x2 = w2;
         if (!fwd) ascii23_of_rc(e.code, x0, x1, x2);
-        const Probe p = probe23_wave<LPP>(ix, active && e.valid, x0, x1, x2, fwd ? e.code : r);
+        const Probe p = probe23_wave<LPP>(ix, active && e.valid, x0, x1, x2, fwd ? e.code : r, true, fg.on);
+        fg.seen(active && e.valid, p.found);
         if (active && e.valid) {
             out.lines = p.lines;
             if (p.found) { out.slot = p.slot; out.tf = p.tf; out.strand = fwd ? 1u : 2u; }
@@ -138,10 +157,11 @@ __device__ __forceinline__ Q23 query23(const IndexDev& ix, bool active, uint64_t
         }
         return out;
     }
-    const Probe f = probe23_wave<LPP>(ix, active, w0, w1, w2, e.code, e.valid);   // raw bytes hashed, sanitised code compared
+    const Probe f = probe23_wave<LPP>(ix, active, w0, w1, w2, e.code, e.valid, fg.on);   // raw bytes hashed, sanitised code compared
     uint64_t r0, r1, r2;
     ascii23_of_rc(e.code, r0, r1, r2);                          // decode(reverseDNA(u)), :615-616
-    const Probe g = probe23_wave<LPP>(ix, active && !f.found, r0, r1, r2, r);
+    const Probe g = probe23_wave<LPP>(ix, active && !f.found, r0, r1, r2, r, true, fg.on);
+    fg.seen(active, f.found || g.found);
     if (active) {
         out.lines = f.lines;
         if (f.found) { out.slot = f.slot; out.tf = f.tf; out.strand = 1; }
@@ -155,12 +175,12 @@ __device__ __forceinline__ Q23 query23(const IndexDev& ix, bool active, uint64_t
 
 // get_tf_both_directions_23mer (python_wrapper.cpp:1259-1275): Q1(q) and Q1(decode(rc(q))); wave-cooperative like query23
 template <bool CANON, int LPP>
-__device__ __forceinline__ void both23(const IndexDev& ix, bool active, uint64_t w0, uint64_t w1, uint64_t w2, uint32_t& fwd, uint32_t& rc) {
+__device__ __forceinline__ void both23(const IndexDev& ix, bool active, uint64_t w0, uint64_t w1, uint64_t w2, uint32_t& fwd, uint32_t& rc, FilterGauge& fg) {
     const Enc23 e = encode23_words(w0, w1, w2);
     const uint64_t r = revcomp(e.code, 23);
     fwd = 0; rc = 0;
     const bool fast = CANON && e.valid;                         // canonical index, pure-ACGT query: both directions see the one canonical key
-    const Q23 q = query23<CANON, LPP>(ix, active && fast, w0, w1, w2);
+    const Q23 q = query23<CANON, LPP>(ix, active && fast, w0, w1, w2, fg);
     if (active && fast) { fwd = q.tf; rc = q.tf; }
     const bool slow = active && !fast;
     if (CANON) {
@@ -181,9 +201,10 @@ __device__ __forceinline__ void both23(const IndexDev& ix, bool active, uint64_t
     uint64_t r0, r1, r2, s0, s1, s2;
     ascii23_of_rc(e.code, r0, r1, r2);
     ascii23_of_rc(r, s0, s1, s2);
-    const Probe F = probe23_wave<LPP>(ix, slow, w0, w1, w2, e.code, e.valid);
-    const Probe R = probe23_wave<LPP>(ix, slow, r0, r1, r2, r);
-    const Probe S2 = probe23_wave<LPP>(ix, slow && !e.valid, s0, s1, s2, e.code);
+    const Probe F = probe23_wave<LPP>(ix, slow, w0, w1, w2, e.code, e.valid, fg.on);
+    const Probe R = probe23_wave<LPP>(ix, slow, r0, r1, r2, r, true, fg.on);
+    const Probe S2 = probe23_wave<LPP>(ix, slow && !e.valid, s0, s1, s2, e.code, true, fg.on);
+    fg.seen(slow, F.found || R.found);
     if (slow) {
         const Probe S = e.valid ? F : S2;
         fwd = F.found ? F.tf : (R.found ? R.tf : 0u);
@@ -198,15 +219,16 @@ __device__ __forceinline__ void both23(const IndexDev& ix, bool active, uint64_t
 
 template <int MODE, bool CANON, int LPP>
 __global__ void __launch_bounds__(kBlock) k_lookup23_ascii(const IndexDev ix, const uint8_t* __restrict__ q, uint64_t N, LookupOut out) {
+    FilterGauge fg;
     AIX_WAVE_LOOP(i, N) {
         const bool in = i < N;
         uint64_t w0 = 0, w1 = 0, w2 = 0;
         if (in) load23(q + 23 * i, w0, w1, w2);
         if (MODE == MODE_TF) {
-            const uint32_t v = query23<CANON, LPP>(ix, in, w0, w1, w2).tf;
+            const uint32_t v = query23<CANON, LPP>(ix, in, w0, w1, w2, fg).tf;
             if (in) out.tf[i] = v;
         } else if (MODE == MODE_LINES) {
-            const uint32_t v = query23<CANON, LPP>(ix, in, w0, w1, w2).lines;   // instrumentation: records read for this query
+            const uint32_t v = query23<CANON, LPP>(ix, in, w0, w1, w2, fg).lines;   // instrumentation: records read for this query
             if (in) out.tf[i] = v;
         } else if (MODE == MODE_HASH) {
             if (in) {
@@ -215,14 +237,14 @@ __global__ void __launch_bounds__(kBlock) k_lookup23_ascii(const IndexDev ix, co
                 out.u64a[i] = mphf_from_hash(ix.m, a, b, c);
             }
         } else if (MODE == MODE_KIDSTRAND) {
-            const Q23 r = query23<CANON, LPP>(ix, in, w0, w1, w2);
+            const Q23 r = query23<CANON, LPP>(ix, in, w0, w1, w2, fg);
             if (in) {
                 if (out.u64a) out.u64a[i] = r.slot;             // get_kid_by_kmer: 0 when absent (:700-716)
                 if (out.strand) out.strand[i] = (uint8_t)r.strand;
             }
         } else {
             uint32_t f, r;
-            both23<CANON, LPP>(ix, in, w0, w1, w2, f, r);
+            both23<CANON, LPP>(ix, in, w0, w1, w2, f, r, fg);
             if (in) {
                 if (MODE == MODE_TOTAL) {
                     out.u64a[i] = (uint64_t)f + (uint64_t)r;
@@ -237,6 +259,7 @@ __global__ void __launch_bounds__(kBlock) k_lookup23_ascii(const IndexDev ix, co
 
 template <bool CANON, int LPP>
 __global__ void __launch_bounds__(kBlock) k_lookup23_codes(const IndexDev ix, const uint64_t* __restrict__ codes, uint64_t N, uint32_t* __restrict__ out) {
+    FilterGauge fg;
     AIX_WAVE_LOOP(i, N) {
         const bool in = i < N;
         const uint64_t u = in ? (codes[i] & ((1ULL << 46) - 1)) : 0ull;
@@ -246,13 +269,15 @@ __global__ void __launch_bounds__(kBlock) k_lookup23_codes(const IndexDev ix, co
         if (CANON) {
             const uint64_t key = u <= r ? u : r;
             ascii23_of_rc(u <= r ? r : u, w0, w1, w2);           // string of `key`
-            const Probe p = probe23_wave<LPP>(ix, in, w0, w1, w2, key);
+            const Probe p = probe23_wave<LPP>(ix, in, w0, w1, w2, key, true, fg.on);
+            fg.seen(in, p.found);
             tf = p.found ? p.tf : 0u;
         } else {
             ascii23_of_rc(r, w0, w1, w2);
-            const Probe f = probe23_wave<LPP>(ix, in, w0, w1, w2, u);
+            const Probe f = probe23_wave<LPP>(ix, in, w0, w1, w2, u, true, fg.on);
             ascii23_of_rc(u, w0, w1, w2);
-            const Probe g = probe23_wave<LPP>(ix, in && !f.found, w0, w1, w2, r);
+            const Probe g = probe23_wave<LPP>(ix, in && !f.found, w0, w1, w2, r, true, fg.on);
+            fg.seen(in, f.found || g.found);
             tf = f.found ? f.tf : (g.found ? g.tf : 0u);
         }
         if (in) out[i] = tf;
@@ -373,6 +398,7 @@ template <bool CANON, int LPP>
 __global__ void __launch_bounds__(kBlock) k_coverage(const IndexDev ix, const uint8_t* __restrict__ seqs, const uint64_t* __restrict__ offs, uint64_t M,
                                                     uint64_t total, uint32_t cutoff, uint32_t* __restrict__ out, const uint64_t* __restrict__ out_offs) {
     const uint32_t k = ix.k;
+    FilterGauge fg;
     AIX_WAVE_LOOP(p, total) {
         // sequence containing byte p: largest s with offs[s] <= p. The lanes of a wave hold consecutive p, so the binary search
         // runs once per wave for its first position (wave-uniform: scalar loads), and a lane then walks forward from there —
@@ -403,7 +429,7 @@ __global__ void __launch_bounds__(kBlock) k_coverage(const IndexDev ix, const ui
         if (k == 23) {
             uint64_t w0 = 0, w1 = 0, w2 = 0;
             if (active) load23(seqs + p, w0, w1, w2);
-            tf = query23<CANON, LPP>(ix, active, w0, w1, w2).tf;
+            tf = query23<CANON, LPP>(ix, active, w0, w1, w2, fg).tf;
         } else if (active) {
             uint64_t w0, w1;
             load13(seqs + p, w0, w1);
@@ -488,7 +514,7 @@ __global__ void __launch_bounds__(kBlock) k_bk_init(BkEntry* __restrict__ bk, ui
     }
 }
 __global__ void __launch_bounds__(kBlock) k_bk_fill(const MphfDev m, const KeyRec* __restrict__ keys, uint64_t n, BkEntry* __restrict__ bk, uint32_t nb,
-                                                   uint32_t* __restrict__ fill) {
+                                                   uint32_t* __restrict__ fill, uint64_t* __restrict__ bloom, uint32_t nbloom) {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         const KeyRec kr = keys[i];
@@ -497,6 +523,7 @@ __global__ void __launch_bounds__(kBlock) k_bk_fill(const MphfDev m, const KeyRe
         ascii23_of_rc(revcomp(kr.code, 23), w0, w1, w2);
         jenkins23(w0, w1, w2, m.seed, a, b, c);
         if (mphf_from_hash(m, a, b, c) != i) continue;         // not where the MPHF puts it: the reference cannot find it, neither can a probe
+        if (bloom) atomicOr((unsigned long long*)&bloom[bloom_word(b, nbloom)], (unsigned long long)bloom_mask(c));
         const uint32_t bi = bucket_of(a, nb);
         const uint32_t pos = atomicAdd(&fill[bi], 1u);
         if (pos < 8u) {
@@ -611,6 +638,7 @@ __global__ void __launch_bounds__(kBlock) k_count23_fixed(const IndexDev ix, con
     if (len < 23) return;
     const uint64_t nwin = len - 22;
     IndexDev ixn = ix;
+    ixn.bloom = nullptr;          // no absence filter in front of the table: it would be one more read for nearly every window
     ixn.early_exit = 0;           // windows of reads drawn from the indexed genome are mostly hits. With the verification table: one line
                                   // per window; without it (and for the overflow fall-back): the parallel three-read evaluation, whose
                                   // fingerprint (same 16 bytes as the pairs) still spares the key-record read of a window that is NOT a key
@@ -629,6 +657,34 @@ __global__ void __launch_bounds__(kBlock) k_count23_fixed(const IndexDev ix, con
         ascii23_of_rc(revcomp(key, 23), s0, s1, s2);
         const Probe pr = probe23_wave<LPP>(ixn, in && e.valid, s0, s1, s2, key);
         if (pr.found) atomicAdd(&tf_out[pr.slot], 1u);
+    }
+}
+
+// count23 without global atomics, front end: the MPHF slot of every window (0xFFFFFFFF: not a key / not a clean window) as a
+// coalesced 4-byte stream; aix_count13.hip's chunked-partition + LDS histogram then adds the stream into tf[] (1.3e9 scattered
+// memory-side atomics per 10 M reads run at ~23 G/s and were what bounded k_count23_fixed once a probe cost one line).
+template <int LPP>
+__global__ void __launch_bounds__(kBlock) k_probe23_slots(const IndexDev ix, const uint8_t* __restrict__ buf, uint64_t len, int canon_mode, uint32_t* __restrict__ slots) {
+    if (len < 23) return;
+    const uint64_t nwin = len - 22;
+    IndexDev ixn = ix;
+    ixn.bloom = nullptr;
+    ixn.early_exit = 0;
+    AIX_WAVE_LOOP(p, nwin) {
+        const bool in = p < nwin;
+        uint64_t w0 = 0, w1 = 0, w2 = 0;
+        if (in) load23(buf + p, w0, w1, w2);
+        w0 = u_to_t(w0 & 0xDFDFDFDFDFDFDFDFULL);
+        w1 = u_to_t(w1 & 0xDFDFDFDFDFDFDFDFULL);
+        w2 = u_to_t(w2 & 0x00DFDFDFDFDFDFDFULL);
+        const Enc23 e = encode23_words(w0, w1, w2);
+        uint64_t key = e.code;
+        if (canon_mode == 1) { const uint64_t x = revcomp_refx86(e.code, 23); key = e.code < x ? e.code : x; }
+        else if (canon_mode == 2) { const uint64_t x = revcomp(e.code, 23); key = e.code < x ? e.code : x; }
+        uint64_t s0, s1, s2;
+        ascii23_of_rc(revcomp(key, 23), s0, s1, s2);
+        const Probe pr = probe23_wave<LPP>(ixn, in && e.valid, s0, s1, s2, key);
+        if (in) slots[p] = pr.found ? (uint32_t)pr.slot : 0xFFFFFFFFu;
     }
 }
 
@@ -867,10 +923,10 @@ hipError_t launch_set_fingerprints(const MphfDev& m, BvRec* recs_rw, EeRec* ee_r
     hipLaunchKernelGGL(k_init_ee, dim3(grid_for(m.nrecs)), dim3(kBlock), 0, s, (const BvRec*)recs_rw, m.nrecs, ee_rw);
     AIX_LAUNCH(k_set_fp, n, s, m, recs_rw, ee_rw, keys, n);
 }
-hipError_t launch_build_buckets(const MphfDev& m, const KeyRec* keys, uint64_t n, BkEntry* bk, uint32_t nb, uint32_t* fill, hipStream_t s) {
+hipError_t launch_build_buckets(const MphfDev& m, const KeyRec* keys, uint64_t n, BkEntry* bk, uint32_t nb, uint32_t* fill, uint64_t* bloom, uint32_t nbloom, hipStream_t s) {
     if (n == 0 || nb == 0) return hipSuccess;
     hipLaunchKernelGGL(k_bk_init, dim3(grid_for((uint64_t)nb * 8)), dim3(kBlock), 0, s, bk, (uint64_t)nb * 8);
-    hipLaunchKernelGGL(k_bk_fill, dim3(grid_for(n)), dim3(kBlock), 0, s, m, keys, n, bk, nb, fill);
+    hipLaunchKernelGGL(k_bk_fill, dim3(grid_for(n)), dim3(kBlock), 0, s, m, keys, n, bk, nb, fill, bloom, nbloom);
     AIX_LAUNCH(k_bk_flag, nb, s, bk, nb, (const uint32_t*)fill);
 }
 hipError_t launch_scatter23(const MphfDev& m, uint64_t n, uint64_t nslots, const uint8_t* keys, const uint64_t* codes, const uint32_t* counts, uint64_t* checker, uint32_t* tf,
@@ -901,6 +957,16 @@ static hipError_t count23_lpp(const IndexDev& ix, const uint8_t* buf, uint64_t l
 hipError_t launch_count23_fixed(const IndexDev& ix, const uint8_t* buf, uint64_t len, int canon_mode, uint32_t* tf_out, hipStream_t s) {
     if (len < 23 || ix.n == 0) return hipSuccess;
 #define AIX_CALL(L) count23_lpp<L>(ix, buf, len, canon_mode, tf_out, s)
+    AIX_LPP_SWITCH(ix.bk_lpp, AIX_CALL)
+#undef AIX_CALL
+}
+template <int LPP>
+static hipError_t probe23_slots_lpp(const IndexDev& ix, const uint8_t* buf, uint64_t len, int canon_mode, uint32_t* slots, hipStream_t s) {
+    AIX_LAUNCH(k_probe23_slots<LPP>, len - 22, s, ix, buf, len, canon_mode, slots);
+}
+hipError_t launch_probe23_slots(const IndexDev& ix, const uint8_t* buf, uint64_t len, int canon_mode, uint32_t* slots, hipStream_t s) {
+    if (len < 23 || ix.n == 0) return hipSuccess;
+#define AIX_CALL(L) probe23_slots_lpp<L>(ix, buf, len, canon_mode, slots, s)
     AIX_LPP_SWITCH(ix.bk_lpp, AIX_CALL)
 #undef AIX_CALL
 }

@@ -155,6 +155,10 @@ class Index:
         """Verification table on / off (answers are identical); lanes = lanes sharing one bucket read (8, 4, 2, 1; 0 = keep)."""
         check(lib().aix_index_set_bucket_table(self._h, int(enabled), lanes))
 
+    def set_absence_filter(self, enabled: bool):
+        """Blocked Bloom filter in front of the verification table on / off (answers are identical)."""
+        check(lib().aix_index_set_absence_filter(self._h, int(enabled)))
+
     def probe_profile(self) -> dict:
         """What one probe that FINDS its key reads under the current settings (bench.py's roofline accounting)."""
         i = self.info

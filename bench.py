@@ -387,15 +387,16 @@ def measure_lookup23(ix, g, qset, queries, rank, world, dev, steps, warmup, gath
     li = ix.lines_ascii_t(q).to(torch.int64)
     mphf_recs = float((li & 15).sum().item()) / queries
     key_recs = float(((li >> 4) & 15).sum().item()) / queries
-    completed = float(((li >> 8) & 255).sum().item()) / queries
+    completed = float(((li >> 8) & 15).sum().item()) / queries
+    filter_words = float(((li >> 12) & 15).sum().item()) / queries
     bucket_lines = float((li >> 16).sum().item()) / queries
     del li
     t = kern_ms * 1e-3
     # bytes this kernel REQUESTS: the query in and the answer out (23 + 4), 128 per bucket line, 12 per record of the early-exit
     # walk (pairs + prefix + the presence dword) or 16 per record of the parallel evaluation, 16 per key record
     rec_bytes = 12.0 if info_flag(ix, "early_exit") else 16.0
-    requested = 27.0 + 128.0 * bucket_lines + rec_bytes * mphf_recs + 16.0 * key_recs
-    lines = bucket_lines + mphf_recs + key_recs
+    requested = 27.0 + 8.0 * filter_words + 128.0 * bucket_lines + rec_bytes * mphf_recs + 16.0 * key_recs
+    lines = filter_words + bucket_lines + mphf_recs + key_recs
     ach = requested * queries / t / 1e9
     line_gbs = (lines * 128.0 + 27.0) * queries / t / 1e9
     # the reference algorithm's bytes for the same queries (104 B forward hit, 204 B reverse hit, 200 B miss, + 27 B streamed)
@@ -403,7 +404,7 @@ def measure_lookup23(ix, g, qset, queries, rank, world, dev, steps, warmup, gath
     roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
             "kernel": "k_lookup23_ascii", "kernel_ms": kern_ms, "queries_per_launch": queries,
             "requested_bytes_per_query": requested,
-            "note": "achieved = bytes the kernel requests (27 streamed + 128 per bucket line + 12/16 per MPHF record + 16 per key record, as "
+            "note": "achieved = bytes the kernel requests (27 streamed + 8 per absence-filter word + 128 per bucket line + 12/16 per MPHF record + 16 per key record, as "
                     "counted by an instrumented launch) x queries / launch time; every random access moves a whole 128-byte line, see line_traffic",
             "line_traffic": {"GBps": line_gbs, "frac": line_gbs / HBM_PEAK_GBS, "lines_per_query": lines,
                              "note": "128-byte lines x accesses + streamed bytes, per second (estimate from the instrumented launch; `traffic` is the "
@@ -417,7 +418,7 @@ def measure_lookup23(ix, g, qset, queries, rank, world, dev, steps, warmup, gath
         roof["random_read"] = {"peak_accesses_per_s": peak_acc, "achieved_accesses_per_s": acc, "frac": acc / peak_acc, "accesses_per_query": lines,
                                "note": "north_star's yardstick: peak = k_gather, uniform-random 16-byte reads over a 4 GiB table in HBM (SURVEY 8d-ii), "
                                        "measured in this run; accesses served by L2 / Infinity Cache can push the ratio above 1"}
-    tr = load_pmc_traffic("lookup23:" + qset, queries_per_launch=queries, bucket_table=int(info["bucket_table"]))
+    tr = load_pmc_traffic("lookup23:" + qset, queries_per_launch=queries, bucket_table=int(info["bucket_table"]), absence_filter=int(info["absence_filter_words"] > 0))
     if tr:
         roof["traffic"] = tr.get("bytes_per_launch")
         roof["traffic_source"] = tr.get("source")
@@ -427,6 +428,7 @@ def measure_lookup23(ix, g, qset, queries, rank, world, dev, steps, warmup, gath
            "query_set": qset, "query_seed": 8 if qset == "Q_mix" else 7, "queries_per_step_per_gpu": queries, "index_keys": ix.n,
            "hit_fraction": hf, "bucket_table": bool(info["bucket_table"]), "bucket_lanes": info["bucket_lanes"], "buckets": info["buckets"],
            "bucket_unfiled_keys": info["bucket_unfiled_keys"], "canonical_only": bool(info["canonical_only"]),
+           "absence_filter_words": info["absence_filter_words"], "filter_words_per_query": filter_words,
            "bucket_lines_per_query": bucket_lines, "mphf_records_read_per_query": mphf_recs, "key_records_read_per_query": key_recs,
            "completed_evaluations_per_query": completed, "index_hbm_bytes": info["device_bytes"]}
     return {"value": world * queries * steps / wall, "ms_per_step": wall / steps * 1e3, "roofline": roof, "config": cfg, "_q": q, "_res": res}
@@ -445,6 +447,8 @@ def apply_ab_switches(ix, a):
         _FLAGS[(id(ix), "early_exit")] = False
     if a.no_bucket_table or a.bucket_lanes:
         ix.set_bucket_table(not a.no_bucket_table, a.bucket_lanes)
+    if a.no_absence_filter:
+        ix.set_absence_filter(False)
 
 
 def info_flag(ix, name):
@@ -578,6 +582,7 @@ def main():
     ap.add_argument("--no-fingerprint", action="store_true", help="disable the 4-bit fingerprint filter")
     ap.add_argument("--no-early-exit", action="store_true", help="disable the early-exit MPHF walk (presence masks)")
     ap.add_argument("--no-bucket-table", action="store_true", help="switch the verification table off (every probe through the MPHF records + key records)")
+    ap.add_argument("--no-absence-filter", action="store_true", help="switch the Bloom filter in front of the verification table off")
     ap.add_argument("--bucket-lanes", type=int, default=0, choices=[0, 1, 2, 4, 8], help="lanes that share one bucket read (0: the library's default)")
     ap.add_argument("--gpu-builder", action="store_true", help="build the MPHF on the GPU (parallel peeling) instead of the host")
     ap.add_argument("--query-mix", action="store_true", help="Q_mix: 50 %% genome windows on a random strand + 50 %% random (seed 8)")

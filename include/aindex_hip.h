@@ -61,7 +61,7 @@ typedef struct {
     uint64_t buckets;         /* its 128-byte buckets (0: not built)                           */
     uint64_t bucket_unfiled_keys; /* keys beyond the eighth of their bucket (MPHF path)        */
     uint32_t bucket_lanes;    /* lanes that share one bucket read (8, 4, 2 or 1)               */
-    uint32_t reserved;
+    uint32_t absence_filter_words; /* 64-bit words of the absence filter in front of the table (0: off) */
 } aix_info_t;
 
 const char* aix_version(void);
@@ -109,6 +109,10 @@ int aix_index_set_early_exit(aix_index_t* h, int enabled);
  * three MPHF records + a key record; answers are identical with it on or off (A/B measurements, tests).
  * lanes: how many lanes share one bucket read (8, 4, 2, 1; 0 = keep). */
 int aix_index_set_bucket_table(aix_index_t* h, int enabled, int lanes);
+/* Absence filter in front of the verification table (lookups, coverage): a blocked Bloom filter of the filed keys, one cached
+ * 8-byte read that answers most absent keys before the table is touched (AIX_BLOOM_BITS bits per key at open, default 16,
+ * 0 = none). Off / on for A/B measurements; answers are identical. */
+int aix_index_set_absence_filter(aix_index_t* h, int enabled);
 /* replace the tf table of a 13-mer handle (u64[4^13], mphf order, HOST pointer) */
 int aix_index_set_tf_13(aix_index_t* h, const uint64_t* tf);
 /* copy tf out (HOST pointer): 23 -> u32[n]; 13 -> u64[4^13] in mphf order

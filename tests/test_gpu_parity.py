@@ -1091,8 +1091,52 @@ def test_early_exit_walk_on_off(canon_case, ix23, q23):
     li = ix.lines_ascii_t(engine.synth_kmers_t(7, 200_000, 23)).cpu().numpy()
     assert 1.0 <= float((li & 15).mean()) < 2.0          # MPHF path: absent keys stop after ~1.35 records on average
     ix.set_bucket_table(True)
+    ix.set_absence_filter(False)
     li = ix.lines_ascii_t(engine.synth_kmers_t(7, 200_000, 23)).cpu().numpy()
     assert float((li >> 16).mean()) == 1.0 and float((li & 15).mean()) < 0.2   # table on: one bucket line; the MPHF only behind an overflowed bucket
+    ix.set_absence_filter(True)
+    li = ix.lines_ascii_t(engine.synth_kmers_t(7, 200_000, 23)).cpu().numpy()
+    assert float(((li >> 12) & 15).mean()) == 1.0 and float((li >> 16).mean()) < 0.05   # filter on: one cached word, absent keys rarely reach the table
+
+
+def test_count23_histogram_backend_equals_atomics_and_oracle(canon_case, small23_prefix, monkeypatch):
+    """k_count23_fixed's two back ends: one memory-side atomic per found window, or the slot stream + chunked-partition LDS
+    histogram (no global atomics; the default for long buffers). Forced onto small inputs here, in one piece and cut into
+    pieces at awkward places: same histogram as the atomics path and as the oracle, in every canonical mode; and the call
+    ACCUMULATES into the caller's table (two calls = twice the counts)."""
+    import torch
+    orc = canon_case["orc"]
+    asc = synth.genome_ascii(23, 300_000)
+    reads = synth.reads_plain(41, asc, 4000, 150, rc_fraction_half=True, n_rate_ppm=1000).tobytes()
+    noisy = bytes(asc[5000:9000]).lower() + b"\n" + bytes(asc[100:400]).replace(b"C", b"R", 2) + b"~U" + bytes(asc[900:1300]) + b"\n" + reads[:60_000]
+    gold_reads = open(small23_prefix + ".reads", "rb").read()
+    cases = [(canon_case["ix"], orc, reads), (canon_case["ix"], orc, noisy)]
+    with Index.open_23(small23_prefix + ".pf", small23_prefix + ".tf.bin", small23_prefix + ".kmers.bin") as gix:
+        cases.append((gix, O.OracleIndex23.from_prefix(small23_prefix), gold_reads))
+        for ix, o, buf in cases:
+            for mode in (0, 1, 2):
+                want = o.count23_fixed(buf, False, mode)
+                monkeypatch.setenv("AIX_COUNT23_ATOMICS", "1")
+                assert np.array_equal(ix.count23_fixed(buf, _lib.FMT_PLAIN, mode), want)
+                monkeypatch.delenv("AIX_COUNT23_ATOMICS")
+                monkeypatch.setenv("AIX_COUNT23_HIST_MIN", "0")
+                for piece in (None, "1000", "77777"):
+                    if piece is None:
+                        monkeypatch.delenv("AIX_COUNT23_PIECE", raising=False)
+                    else:
+                        monkeypatch.setenv("AIX_COUNT23_PIECE", piece)
+                    for bk in (True, False):
+                        ix.set_bucket_table(bk)
+                        assert np.array_equal(ix.count23_fixed(buf, _lib.FMT_PLAIN, mode), want), (mode, piece, bk)
+                ix.set_bucket_table(True)
+                monkeypatch.delenv("AIX_COUNT23_PIECE", raising=False)
+                t = torch.frombuffer(bytearray(buf), dtype=torch.uint8).cuda()
+                acc = torch.zeros(ix.n, dtype=torch.int32, device="cuda")
+                ix.count23_fixed_t(t, mode, acc)
+                ix.count23_fixed_t(t, mode, acc)
+                torch.cuda.synchronize()
+                assert np.array_equal(acc.cpu().numpy().view(np.uint32), 2 * want)
+                monkeypatch.delenv("AIX_COUNT23_HIST_MIN")
 
 
 def test_bucket_table_every_consumer_on_off_and_overflowing(canon_case, small23_prefix, monkeypatch):
@@ -1137,7 +1181,8 @@ def test_bucket_table_every_consumer_on_off_and_overflowing(canon_case, small23_
                     assert np.array_equal(base["ind"], oind) and np.array_equal(base["pos"], opos)
                 for lanes in (8, 4, 2, 1):
                     ix.set_bucket_table(True, lanes)
-                    assert ix.info["bucket_lanes"] == lanes
+                    ix.set_absence_filter(lanes != 4)                        # the absence filter in front of the table: on, and off once
+                    assert ix.info["bucket_lanes"] == lanes and (ix.info["absence_filter_words"] > 0) == (lanes != 4)
                     got = answers(ix)
                     for k, v in base.items():
                         assert np.array_equal(got[k], v), (load, pre, lanes, k)
