@@ -6,12 +6,15 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/aindex_hip.h"
@@ -88,6 +91,8 @@ struct aix_index {
     std::mutex small_mutex;
     hipStream_t small_stream = nullptr;
     void* pin_cov = nullptr;                   // pinned, device-mapped staging of small coverage requests (kCovPin bytes)
+    struct HostPipe* pipe = nullptr;           // pinned staging + streams of the large host-buffer batches (lazily built)
+    std::mutex pipe_mutex;
     hipEvent_t work13_done = nullptr;          // recorded behind every counting call: the next one (any stream) waits for it before touching the workspace
     uint64_t device_bytes = 0;
     bool perm13_bijective = false;             // 13-mer: code -> mphf slot is a bijection of [0, 4^13) (true for the all-13-mers .pf)
@@ -240,6 +245,8 @@ static int check_device(int device) {
     return AIX_OK;
 }
 
+static void free_host_pipe(struct HostPipe* p);
+
 static void destroy(aix_index* h) {
     if (!h) return;
     DevGuard g(h->device);
@@ -253,6 +260,7 @@ static void destroy(aix_index* h) {
     if (h->perm13) (void)hipFree(h->perm13);
     if (h->scratch13) (void)hipFree(h->scratch13);
     if (h->work13) (void)hipFree(h->work13);
+    if (h->pipe) { free_host_pipe(h->pipe); h->pipe = nullptr; }
     if (h->work13_done) (void)hipEventDestroy(h->work13_done);
     if (h->small_stream) (void)hipStreamDestroy(h->small_stream);
     if (h->pin_in) (void)hipHostFree(h->pin_in);
@@ -857,9 +865,159 @@ extern "C" int aix_synth_reads_dev(uint64_t seed, const char* d_genome, uint64_t
 }
 
 // ---------------------------------------------------------------------------------------------
+// host memory <-> pinned staging with several threads (one thread moves ~10 GB/s; PCIe 5 x16 wants ~50)
+// ---------------------------------------------------------------------------------------------
+namespace {
+class CopyPool {
+    struct Job { char* dst; const char* src; size_t bytes; };
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::vector<Job> jobs;
+    size_t pending = 0;
+    bool stop = false;
+    void run() {
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return stop || !jobs.empty(); });
+                if (stop && jobs.empty()) return;
+                j = jobs.back();
+                jobs.pop_back();
+            }
+            memcpy(j.dst, j.src, j.bytes);
+            std::lock_guard<std::mutex> lk(mu);
+            if (--pending == 0) cv_done.notify_all();
+        }
+    }
+
+public:
+    explicit CopyPool(unsigned n) { for (unsigned i = 0; i < n; ++i) workers.emplace_back([this] { run(); }); }
+    ~CopyPool() {
+        { std::lock_guard<std::mutex> lk(mu); stop = true; }
+        cv_work.notify_all();
+        for (auto& t : workers) t.join();
+    }
+    unsigned size() const { return (unsigned)workers.size(); }
+    // one copy at a time per pool user (callers hold their handle's pipe mutex; the pool itself serialises with `busy`)
+    std::mutex busy;
+    void copy(void* dst, const void* src, size_t bytes) {
+        const size_t parts = workers.size() + 1;
+        if (bytes < (4u << 20) || parts == 1) { memcpy(dst, src, bytes); return; }
+        std::lock_guard<std::mutex> only(busy);
+        const size_t slice = ((bytes + parts - 1) / parts + 4095) & ~(size_t)4095;
+        size_t off = slice;                                  // the caller takes the first slice itself
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (; off < bytes; off += slice) { jobs.push_back(Job{(char*)dst + off, (const char*)src + off, std::min(slice, bytes - off)}); ++pending; }
+        }
+        cv_work.notify_all();
+        memcpy(dst, src, std::min(slice, bytes));
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+};
+CopyPool& copy_pool() {
+    static CopyPool pool([] {
+        unsigned n = std::thread::hardware_concurrency();
+        n = n ? std::min(16u, std::max(1u, n / 2)) : 4u;
+        if (const char* e = getenv("AIX_HOST_COPY_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) n = (unsigned)v; }
+        return n - 1;                                        // + the calling thread
+    }());
+    return pool;
+}
+}  // namespace
+
+// Large host-buffer batches: three staging sets (pinned host + device buffers + a stream + an event each). While set b's
+// chunk is on the wire / in the kernel, the host threads fill the next set and drain the one before: H2D, kernel, D2H and the
+// two host copies of different chunks overlap. (Round 1 staged synchronously from pageable memory: 25-35 GB/s in.)
+struct HostPipe {
+    static constexpr int S = 3;
+    static constexpr uint64_t kChunkQ = 2ull << 20;          // queries per chunk
+    static constexpr uint64_t kInBytes = kChunkQ * 23 + 64, kOutBytes = kChunkQ * 8;
+    void* hin[S] = {};
+    void* din[S] = {};
+    void* hout[S][3] = {};
+    void* dout[S][3] = {};
+    hipStream_t st[S] = {};
+    hipEvent_t ev[S] = {};
+    bool ok = false;
+    int init() {
+        for (int b = 0; b < S; ++b) {
+            if (hipHostMalloc(&hin[b], kInBytes, hipHostMallocDefault) != hipSuccess) return AIX_ERR_NOMEM;
+            if (hipMalloc(&din[b], kInBytes) != hipSuccess) return AIX_ERR_NOMEM;
+            if (hipStreamCreateWithFlags(&st[b], hipStreamNonBlocking) != hipSuccess) return AIX_ERR_HIP;
+            if (hipEventCreateWithFlags(&ev[b], hipEventDisableTiming) != hipSuccess) return AIX_ERR_HIP;
+        }
+        ok = true;
+        return AIX_OK;
+    }
+    int need_out(int j) {
+        for (int b = 0; b < S; ++b) {
+            if (hout[b][j]) continue;
+            if (hipHostMalloc(&hout[b][j], kOutBytes, hipHostMallocDefault) != hipSuccess) return AIX_ERR_NOMEM;
+            if (hipMalloc(&dout[b][j], kOutBytes) != hipSuccess) return AIX_ERR_NOMEM;
+        }
+        return AIX_OK;
+    }
+    ~HostPipe() {
+        for (int b = 0; b < S; ++b) {
+            if (st[b]) (void)hipStreamSynchronize(st[b]);
+            if (hin[b]) (void)hipHostFree(hin[b]);
+            if (din[b]) (void)hipFree(din[b]);
+            for (int j = 0; j < 3; ++j) { if (hout[b][j]) (void)hipHostFree(hout[b][j]); if (dout[b][j]) (void)hipFree(dout[b][j]); }
+            if (ev[b]) (void)hipEventDestroy(ev[b]);
+            if (st[b]) (void)hipStreamDestroy(st[b]);
+        }
+    }
+};
+
+static void free_host_pipe(HostPipe* p) { delete p; }
+
+// in: N elements of in_elem bytes each (host); outs[j]: N elements of out_elem[j] bytes (host, nullable). call(d_in, m, d_out0..2, stream).
+template <typename F>
+static int pipelined_host_batch(aix_index_t* h, const char* in, uint32_t in_elem, uint64_t N, const uint32_t out_elem[3], void* const outs[3], F&& call) {
+    std::lock_guard<std::mutex> lk(h->pipe_mutex);          // one large host batch per handle at a time (they would share the wire anyway)
+    if (!h->pipe) {
+        h->pipe = new (std::nothrow) HostPipe();
+        if (!h->pipe) return AIX_ERR_NOMEM;
+        const int st = h->pipe->init();
+        if (st) { delete h->pipe; h->pipe = nullptr; (void)hipGetLastError(); return st; }
+    }
+    HostPipe& P = *h->pipe;
+    for (int j = 0; j < 3; ++j)
+        if (outs[j]) { const int st = P.need_out(j); if (st) { (void)hipGetLastError(); return st; } }
+    CopyPool& pool = copy_pool();
+    const uint64_t chunk = HostPipe::kChunkQ;
+    const uint64_t nchunks = (N + chunk - 1) / chunk;
+    auto drain = [&](uint64_t c) -> int {                    // chunk c has completed on the device: hand its answers to the caller
+        const int b = (int)(c % HostPipe::S);
+        HIPCHK(hipEventSynchronize(P.ev[b]));
+        const uint64_t lo = c * chunk, m = std::min(chunk, N - lo);
+        for (int j = 0; j < 3; ++j)
+            if (outs[j]) pool.copy((char*)outs[j] + lo * out_elem[j], P.hout[b][j], m * out_elem[j]);
+        return AIX_OK;
+    };
+    for (uint64_t c = 0; c < nchunks; ++c) {
+        const int b = (int)(c % HostPipe::S);
+        if (c >= (uint64_t)HostPipe::S) { const int st = drain(c - HostPipe::S); if (st) return st; }
+        const uint64_t lo = c * chunk, m = std::min(chunk, N - lo);
+        pool.copy(P.hin[b], in + lo * in_elem, m * in_elem);
+        HIPCHK(hipMemcpyAsync(P.din[b], P.hin[b], m * in_elem, hipMemcpyHostToDevice, P.st[b]));
+        const int st = call((const char*)P.din[b], m, P.dout[b][0], P.dout[b][1], P.dout[b][2], (void*)P.st[b]);
+        if (st) { for (int i = 0; i < HostPipe::S; ++i) (void)hipStreamSynchronize(P.st[i]); return st; }
+        for (int j = 0; j < 3; ++j)
+            if (outs[j]) HIPCHK(hipMemcpyAsync(P.hout[b][j], P.dout[b][j], m * out_elem[j], hipMemcpyDeviceToHost, P.st[b]));
+        HIPCHK(hipEventRecord(P.ev[b], P.st[b]));
+    }
+    for (uint64_t c = nchunks > (uint64_t)HostPipe::S ? nchunks - HostPipe::S : 0; c < nchunks; ++c) { const int st = drain(c); if (st) return st; }
+    return AIX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // host-pointer twins: stage through HBM in bounded chunks, run the same kernels, copy back
 // ---------------------------------------------------------------------------------------------
-static constexpr uint64_t kChunk = 1ull << 26;   // queries per staging chunk (64 Mi)
 static constexpr uint64_t kSmall = 4096;         // up to here a host batch goes through the pinned, device-mapped staging of the handle
 
 static int ensure_pinned(aix_index_t* h) {
@@ -879,7 +1037,7 @@ static int ensure_pinned(aix_index_t* h) {
 }
 
 template <typename F>
-static int chunked_ascii(aix_index_t* h, const char* kmers, uint64_t N, uint32_t out_elem_bytes[3], void* outs[3], F&& call) {
+static int chunked_ascii(aix_index_t* h, const char* kmers, uint64_t N, const uint32_t out_elem_bytes[3], void* const outs[3], F&& call) {
     if (!h || (N && !kmers)) return AIX_ERR_ARG;
     if (N == 0) return AIX_OK;
     DevGuard g(h->device);
@@ -902,22 +1060,7 @@ static int chunked_ascii(aix_index_t* h, const char* kmers, uint64_t N, uint32_t
             (void)hipGetLastError();
         }
     }
-    const uint64_t k = h->k, chunk = std::min<uint64_t>(N, kChunk);
-    DevBuf dq, d0, d1, d2;
-    HIPCHK(dq.alloc(chunk * k + 8));
-    DevBuf* douts[3] = {&d0, &d1, &d2};
-    for (int j = 0; j < 3; ++j)
-        if (outs[j]) HIPCHK(douts[j]->alloc(chunk * out_elem_bytes[j]));
-    for (uint64_t lo = 0; lo < N; lo += chunk) {
-        const uint64_t m = std::min(chunk, N - lo);
-        HIPCHK(hipMemcpy(dq.p, kmers + lo * k, m * k, hipMemcpyHostToDevice));
-        int st = call((const char*)dq.p, m, d0.p, d1.p, d2.p, nullptr);
-        if (st) return st;
-        HIPCHK(hipStreamSynchronize(0));
-        for (int j = 0; j < 3; ++j)
-            if (outs[j]) HIPCHK(hipMemcpy((char*)outs[j] + lo * out_elem_bytes[j], douts[j]->p, m * out_elem_bytes[j], hipMemcpyDeviceToHost));
-    }
-    return AIX_OK;
+    return pipelined_host_batch(h, kmers, h->k, N, out_elem_bytes, outs, call);
 }
 
 static bool empty23(const aix_index_t* h) { return h && h->k == 23 && h->n == 0; }
@@ -982,19 +1125,11 @@ extern "C" int aix_tf_batch_codes(aix_index_t* h, const uint64_t* codes, uint64_
     if (N == 0) return AIX_OK;
     if (h->n == 0) { memset(out, 0, 4 * N); return AIX_OK; }
     DevGuard g(h->device);
-    const uint64_t chunk = std::min<uint64_t>(N, kChunk);
-    DevBuf dc, dout;
-    HIPCHK(dc.alloc(chunk * 8));
-    HIPCHK(dout.alloc(chunk * 4));
-    for (uint64_t lo = 0; lo < N; lo += chunk) {
-        const uint64_t m = std::min(chunk, N - lo);
-        HIPCHK(hipMemcpy(dc.p, codes + lo, m * 8, hipMemcpyHostToDevice));
-        int st = aix_tf_batch_codes_dev(h, (const uint64_t*)dc.p, m, (uint32_t*)dout.p, nullptr);
-        if (st) return st;
-        HIPCHK(hipStreamSynchronize(0));
-        HIPCHK(hipMemcpy(out + lo, dout.p, m * 4, hipMemcpyDeviceToHost));
-    }
-    return AIX_OK;
+    const uint32_t eb[3] = {4, 0, 0};
+    void* const outs[3] = {out, nullptr, nullptr};
+    return pipelined_host_batch(h, (const char*)codes, 8, N, eb, outs, [&](const char* dq, uint64_t m, void* a, void*, void*, void* st) {
+        return aix_tf_batch_codes_dev(h, (const uint64_t*)dq, m, (uint32_t*)a, st);
+    });
 }
 
 extern "C" int aix_tf_batch_ragged(aix_index_t* h, const char* bytes, const uint64_t* offsets, uint64_t N, uint32_t* out) {

@@ -563,7 +563,7 @@ def main():
                     help="auto: N = 1 -> lookup23 (BASELINE configs[2], the headline), N > 1 -> count23 --scaling strong (configs[3])")
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"], help="count23: strong = --total-reads split over the ranks (config 4); weak = --reads per rank")
     ap.add_argument("--total-reads", type=int, default=200_000_000, help="reads of the strong-scaling counting workload (config 4: 200 M)")
-    ap.add_argument("--seqs", type=int, default=100_000)
+    ap.add_argument("--seqs", type=int, default=1_000_000, help="sequences of the coverage workloads (config 5: 1 M x 10 kbp)")
     ap.add_argument("--seq-len", type=int, default=10_000)
     ap.add_argument("--table-mib", type=int, default=4096)
     ap.add_argument("--elem", type=int, default=16)
@@ -699,14 +699,17 @@ def main():
         res = torch.empty(a.queries, dtype=torch.int32, device=f"cuda:{dev}")
         step = lambda: ix.tf_ascii_t(q, res)
         wall, kern_ms, _ = timed_steps(step, a.steps, a.warmup, dev)
-        bpq = 100.0 + 17.0          # one MPHF evaluation (92 B) + the 8-byte tf + 17 B streamed; ours: ONE 8-byte read of the code-ordered table
+        bpq = 13.0 + 8.0 + 4.0     # what the kernel requests: the query in, ONE 8-byte read of the code-ordered table, the answer out
         achieved = bpq * a.queries / (kern_ms * 1e-3) / 1e9
         out.update({"metric": "kmer_lookups_per_sec_13mer_batch", "value": world * a.queries * a.steps / wall, "unit": "lookups/s",
                     "ms_per_step": wall / a.steps * 1e3, "dtype": "u64",
                     "config": {"workload": "13-mer dense table batch lookup, uniform-random 13-mers", "queries_per_step_per_gpu": a.queries},
                     "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                                 "traffic": None, "kernel": "k_lookup13_ascii", "kernel_ms": kern_ms, "algorithmic_bytes_per_query": bpq,
-                                 "reads_issued": {"bytes_per_query": 25.0, "GBps": 25.0 * a.queries / (kern_ms * 1e-3) / 1e9}}})
+                                 "traffic": None, "kernel": "k_lookup13_ascii", "kernel_ms": kern_ms, "requested_bytes_per_query": bpq,
+                                 "line_traffic": {"GBps": (128.0 + 17.0) * a.queries / (kern_ms * 1e-3) / 1e9,
+                                                  "note": "one 128-byte line per table read + streamed bytes (estimate)"},
+                                 "reference_algorithm": {"bytes_per_query": 117.0, "GBps": 117.0 * a.queries / (kern_ms * 1e-3) / 1e9,
+                                                         "note": "SURVEY 8(d): one MPHF evaluation (92 B) + the 8-byte tf + 17 B streamed; not what this kernel moves"}}})
 
     elif a.workload == "count13":
         from aindex_amd.engine import Index
@@ -720,7 +723,10 @@ def main():
             adist.all_reduce_sum_(tf)
         wall, kern_ms, _ = timed_steps(step, a.steps, a.warmup, dev)
         windows = a.reads * (150 - 12)
-        achieved = (a.reads * 151 + windows * 8.0) / (kern_ms * 1e-3) / 1e9
+        # requested by the three kernels: input once, a 2-byte payload per window written by the split and read by the histogram,
+        # the 4^13 u64 table cleared and written through the permutation (4 B per slot read for the permutation)
+        requested = a.reads * 151 + windows * 4.0 + (4 ** 13) * (8.0 + 8.0 + 4.0)
+        achieved = requested / (kern_ms * 1e-3) / 1e9
         cb = None
         if rank == 0 and world == 1 and not a.no_cpu_baseline:
             cb = cpu_baseline_count13(ix, reads, min(a.cpu_reads, a.reads), os.path.join(cache, "cpu13"), pf13_path())
@@ -729,9 +735,13 @@ def main():
                     "config": {"workload": "configs[1]: 13-mer dense 4^13 table count of 150 bp reads + all-reduce", "reads_per_step_per_gpu": a.reads},
                     **({"cpu_baseline": cb.get("reference", cb["port_mt"]), "cpu_baseline_extra": cb} if cb else {}),
                     "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                                 "traffic": None, "kernel": "k_c13_split_chunked + directory sort + k_c13_hist_chunked (+ memset of the table)", "kernel_ms": kern_ms}})
-        tr = load_pmc_traffic("count13")
-        if tr and tr.get("reads_per_launch") == a.reads:
+                                 "traffic": None, "kernel": "k_c13_split_chunked + directory sort + k_c13_hist_chunked (+ memset of the table)", "kernel_ms": kern_ms,
+                                 "requested_bytes_per_launch": requested, "reads_per_launch": a.reads,
+                                 "note": "not HBM-bound: the split kernel is bound by its LDS atomics (DESIGN.md §5); the fraction says how far from the stream rate it is",
+                                 "reference_algorithm": {"bytes_per_window": 1.09 + 8.0, "GBps": (a.reads * 151 + windows * 8.0) / (kern_ms * 1e-3) / 1e9,
+                                                         "note": "SURVEY 8(d): input + one 8-byte counter RMW per window"}}})
+        tr = load_pmc_traffic("count13", reads_per_launch=a.reads)
+        if tr:
             out["roofline"]["traffic"] = tr.get("bytes_per_launch")
             out["roofline"]["traffic_source"] = tr.get("source")
 
@@ -797,21 +807,29 @@ def main():
         step = lambda: ix.coverage_t(seqs, offs, ooffs, a.seqs * per, 0, outp)
         wall, kern_ms, _ = timed_steps(step, a.steps, a.warmup, dev)
         positions = a.seqs * per
-        achieved = positions * (1.0 + 100.0 + 4.0 + 4.0) / (kern_ms * 1e-3) / 1e9
+        pp = ix.probe_profile()
+        achieved = positions * (1.0 + pp["bytes_per_hit_probe"] + 4.0) / (kern_ms * 1e-3) / 1e9     # 1 B of sequence + one probe + the 4-byte answer per position
         cb = None
         if rank == 0 and world == 1 and not a.no_cpu_baseline:
             cb = cpu_baseline_coverage23(ix, pf, seqs, L, outp, per, 40, os.path.join(cache, "cpucov"))
         out.update({"metric": "sequences_per_sec_coverage_23mer", "value": world * a.seqs * a.steps / wall, "unit": "sequences/s",
                     "ms_per_step": wall / a.steps * 1e3, "dtype": "u64",
                     "config": {"workload": f"configs[4]: per-position tf profile (k=23) of {L} bp sequences drawn from the indexed genome (50 % rc, 0.1 % N)",
-                               "sequences_per_step_per_gpu": a.seqs, "positions_per_step": positions, "nonzero_fraction": float((outp != 0).float().mean().item())},
+                               "sequences_per_step_per_gpu": a.seqs, "positions_per_step": positions, "nonzero_fraction": int(torch.count_nonzero(outp).item()) / outp.numel()},
                     **({"cpu_baseline": cb} if cb else {}),
                     "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                                 "traffic": None, "kernel": "k_coverage", "kernel_ms": kern_ms, "positions_per_sec": positions / (kern_ms * 1e-3)}})
+                                 "traffic": None, "kernel": "k_coverage", "kernel_ms": kern_ms, "positions_per_sec": positions / (kern_ms * 1e-3),
+                                 "positions_per_launch": positions, "probe": pp["name"], "requested_bytes_per_position": 5.0 + pp["bytes_per_hit_probe"],
+                                 "reference_algorithm": {"bytes_per_position": 1.0 + 154.0 + 4.0, "GBps": positions * 159.0 / (kern_ms * 1e-3) / 1e9,
+                                                         "note": "SURVEY 8(d) lookup bytes per window of a present k-mer; not what this kernel moves"}}})
+        tr = load_pmc_traffic("coverage23", positions_per_launch=positions)
+        if tr:
+            out["roofline"]["traffic"] = tr.get("bytes_per_launch")
+            out["roofline"]["traffic_source"] = tr.get("source")
         if not a.no_gather_probe:
             peak_acc = gather_roofline(dev)
             nzf = out["config"]["nonzero_fraction"]
-            acc = 4.0 * nzf + 1.16 * (1.0 - nzf)                      # found windows read 3 MPHF records + the key record, the others stop early
+            acc = pp["lines_per_hit_probe"]                          # one bucket line (or 3 MPHF records + the key record) per position
             ach = positions * acc / (kern_ms * 1e-3)
             out["roofline"]["random_read"] = {"peak_accesses_per_s": peak_acc, "achieved_accesses_per_s": ach, "frac": ach / peak_acc, "accesses_per_position": acc,
                                               "note": "peak = k_gather over a 4 GiB table"}
@@ -836,7 +854,7 @@ def main():
         out.update({"metric": "sequences_per_sec_coverage_13mer", "value": world * a.seqs * a.steps / wall, "unit": "sequences/s",
                     "ms_per_step": wall / a.steps * 1e3, "dtype": "u64",
                     "config": {"workload": f"configs[4]: per-position tf profile (k=13) of {L} bp sequences drawn from the counted genome (0.1 % N)",
-                               "sequences_per_step_per_gpu": a.seqs, "positions_per_step": positions, "nonzero_fraction": float((outp != 0).float().mean().item())},
+                               "sequences_per_step_per_gpu": a.seqs, "positions_per_step": positions, "nonzero_fraction": int(torch.count_nonzero(outp).item()) / outp.numel()},
                     "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                  "traffic": None, "kernel": "k_coverage", "kernel_ms": kern_ms, "positions_per_sec": positions / (kern_ms * 1e-3)}})
 
@@ -914,7 +932,8 @@ def main():
         windows = int(reads_t.numel() - 22)
         # bytes the fill asks for: 23+4 per window (probe: query bytes in, bucket out), 3 x 16 + 16 per probed window, and the
         # radix sort of (bucket, offset) pairs (4 passes x 16 B read + written), 8 B per placed offset
-        achieved = (windows * (1.0 + 4.0 + 64.0 + 4 * 16.0) + 8.0 * int(indices[-1])) / (kern_ms * 1e-3) / 1e9
+        pp = ix.probe_profile()
+        achieved = (windows * (1.0 + 4.0 + pp["bytes_per_hit_probe"] + 4 * 16.0) + 8.0 * int(indices[-1])) / (kern_ms * 1e-3) / 1e9
         out.update({**({"cpu_baseline": cbp} if cbp else {}),
                     "metric": "reads_per_sec_positions_fill_23mer", "value": world * a.reads * a.steps / wall, "unit": "reads/s",
                     "ms_per_step": wall / a.steps * 1e3, "dtype": "u64",

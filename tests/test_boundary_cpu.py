@@ -109,3 +109,15 @@ def test_load_reads_in_memory_and_mapped_agree_with_the_reference_answers(gold, 
     w2 = AindexWrapper()
     w2.load_reads_in_memory(str(tmp_path / "missing.reads"))                          # :337-340: message, early return
     assert w2.reads_size == 0 and w2.get_read_by_rid(0) == ""
+
+
+def test_host_normaliser_against_reference_written_reads_files(gold):
+    """aix_normalize_reads (host side of the readers, count_kmers13.cpp:211-257) pinned directly to reference outputs: the
+    `.reads` files the compiled reference's compute_reads wrote for the same inputs are the PLAIN form, one sequence per line
+    (compute_reads.cpp:118-147 FASTQ line 4i+1, :170-213 FASTA records concatenated over their lines). The device kernels are
+    held to the same files in tests/test_gpu_parity.py::test_normalisers_against_reference_written_reads_files."""
+    from aindex_amd import counting
+    d = os.path.join(gold, "compute_reads")
+    for src, want, fmt in (("in_test.fasta", "fasta.reads", 1), ("../count13/synth.fa", "fasta_multi.reads", 1), ("in_test_se.fastq", "se.reads", 2)):
+        raw = open(os.path.join(d, src), "rb").read()
+        assert counting.normalize(raw, fmt, 0) == open(os.path.join(d, want), "rb").read(), src

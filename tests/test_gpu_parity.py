@@ -802,6 +802,23 @@ def _host_norm(buf, fmt, mode):
     return counting.normalize(buf, fmt, mode)
 
 
+def test_normalisers_against_reference_written_reads_files(gold):
+    """Direct pin of both normalisers (device kernels and the host routine) to REFERENCE outputs: the `.reads` files the
+    compiled reference's compute_reads wrote for the same inputs (tests/golden/compute_reads/, make_golden.py) are exactly
+    the PLAIN form — one sequence per line: FASTA records concatenated over their lines (compute_reads.cpp:170-213 ==
+    count_kmers13.cpp:211-235), FASTQ line 4i+1 (compute_reads.cpp:118-147 == count_kmers13.cpp:240-257)."""
+    import torch
+    from aindex_amd import counting
+    d = os.path.join(gold, "compute_reads")
+    cases = [("in_test.fasta", "fasta.reads", 1), ("../count13/synth.fa", "fasta_multi.reads", 1), ("in_test_se.fastq", "se.reads", 2)]
+    for src, want_name, fmt in cases:
+        raw = open(os.path.join(d, src), "rb").read()
+        want = open(os.path.join(d, want_name), "rb").read()
+        assert counting.normalize(raw, fmt, 0) == want, src
+        t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).cuda()
+        assert counting.normalize_t(t, fmt, 0).cpu().numpy().tobytes() == want, src
+
+
 def test_device_normalisation_equals_host(gold):
     import torch
     from aindex_amd import counting
@@ -879,6 +896,81 @@ def test_count23_sum_equals_valid_windows_at_scale(canon_case):
     assert (strand == 1).all()
     exp[kid.astype(np.int64)] = counts.cpu().numpy()
     assert np.array_equal(tf.cpu().numpy().astype(np.int64), exp)
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json's full sizes, through size-independent properties (the oracle cannot run these in seconds)
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def config3_index():
+    """The index of BASELINE configs[2..4]: ~5e7 true-canonical 23-mers of a synthetic 50 Mbp genome (seed 23), tf = genome
+    multiplicity; keys / counts by the GPU counter, MPHF by the GPU builder, scatter on the device — no host step."""
+    import torch
+    from aindex_amd import engine, counting
+    g = engine.synth_genome_t(23, 50_000_000)
+    keys, counts = counting.count_distinct_t(g, 23, _lib.CANON_TRUE_RC)
+    pf = builder.build_pf_codes_t(keys, 23)
+    ix = Index.build_23_codes_t(pf, keys, counts.to(torch.int32))
+    yield {"ix": ix, "g": g, "keys": keys, "counts": counts}
+    ix.close()
+
+
+def test_config4_share_of_25M_reads_properties(config3_index):
+    """Config 4 at the N = 8 share (25 M reads x 150 bp, seed 41, 50 % reverse strand, 0.1 % N): (i) sum(tf) == the number of
+    windows without N (every such window of a genome read is a key), counted independently with torch; (ii) the histogram is
+    the sort / run-length result of the same reads (multiset of counts, and key by key on a sample through kid lookups);
+    (iii) the atomics back end gives the same table."""
+    import torch
+    from aindex_amd import engine, counting
+    ix, g = config3_index["ix"], config3_index["g"]
+    n_reads = 25_000_000
+    reads = engine.synth_reads_t(41, g, n_reads, 150, rc_half=True, n_rate_ppm=1000)
+    tf = ix.count23_fixed_t(reads, _lib.CANON_TRUE_RC)
+    torch.cuda.synchronize()
+    is_n = (reads.view(n_reads, 151)[:, :150] == ord("N")).to(torch.int16)
+    c = torch.cumsum(is_n, dim=1)
+    inside = c[:, 22:] - torch.cat([torch.zeros(n_reads, 1, dtype=torch.int16, device=c.device), c[:, :-23]], dim=1)
+    valid = int((inside == 0).sum().item())
+    del is_n, c, inside
+    assert int(tf.to(torch.int64).sum().item()) == valid and valid > n_reads * 100
+    keys, counts = counting.count_distinct_t(reads[: 5_000_000 * 151], 23, _lib.CANON_TRUE_RC)       # sort / run-length of the first 5 M reads
+    tf5 = ix.count23_fixed_t(reads[: 5_000_000 * 151], _lib.CANON_TRUE_RC).to(torch.int64)
+    assert torch.equal(torch.sort(tf5[tf5 > 0]).values, torch.sort(counts).values)
+    pick = torch.arange(0, keys.numel(), max(1, keys.numel() // 200_000), device=keys.device)
+    kid, strand = ix.kid_strand_ascii(synth.decode_kmers(keys[pick].cpu().numpy().view(np.uint64), 23))
+    assert (strand == 1).all()
+    assert np.array_equal(tf5.cpu().numpy()[kid.astype(np.int64)], counts[pick].cpu().numpy())
+    os.environ["AIX_COUNT23_ATOMICS"] = "1"
+    try:
+        tf_a = ix.count23_fixed_t(reads, _lib.CANON_TRUE_RC)
+    finally:
+        del os.environ["AIX_COUNT23_ATOMICS"]
+    assert torch.equal(tf_a, tf)
+
+
+def test_config5_coverage_100k_sequences_properties(config3_index, ix13):
+    """Config 5 at a tenth of its size (100 K sequences x 10 kbp; the bench runs the 1 M): the per-position profile equals
+    the batch lookup of every window, checked on sampled sequences, for k = 23 (index of config 3) and k = 13."""
+    import torch
+    from aindex_amd import engine
+    ix, g = config3_index["ix"], config3_index["g"]
+    n_seq, L = 100_000, 10_000
+    for index, k, genome in ((ix, 23, g), (ix13, 13, engine.synth_genome_t(13, 4_000_000))):
+        seqs = engine.synth_reads_t(51, genome, n_seq, L, rc_half=(k == 23), n_rate_ppm=1000)
+        offs = torch.arange(0, (n_seq + 1) * (L + 1), L + 1, dtype=torch.int64, device="cuda")
+        per = (L + 1) - k + 1
+        ooffs = torch.arange(0, (n_seq + 1) * per, per, dtype=torch.int64, device="cuda")
+        prof = index.coverage_t(seqs, offs, ooffs, n_seq * per, 0).view(n_seq, per)
+        torch.cuda.synchronize()
+        assert int((prof[:, L - k + 1:] != 0).sum().item()) == 0                    # windows that reach into the separator
+        rows = seqs.view(n_seq, L + 1)
+        for sidx in (0, 1, 4_999, 50_000, 99_999):
+            win = rows[sidx, :L].unfold(0, k, 1).contiguous().view(-1)               # every window of the sequence, as a query batch
+            want = index.tf_ascii_t(win)
+            assert torch.equal(prof[sidx, : L - k + 1], want), (k, sidx)
+        if k == 23:
+            assert float((prof[:, : L - k + 1] != 0).float().mean().item()) > 0.9    # genome reads: nearly every window is a key
+        del prof, seqs
 
 
 # ------------------------------------------------------------------------------------------------
