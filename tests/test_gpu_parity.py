@@ -962,12 +962,13 @@ def test_config5_coverage_100k_sequences_properties(config3_index, ix13):
         ooffs = torch.arange(0, (n_seq + 1) * per, per, dtype=torch.int64, device="cuda")
         prof = index.coverage_t(seqs, offs, ooffs, n_seq * per, 0).view(n_seq, per)
         torch.cuda.synchronize()
-        assert int((prof[:, L - k + 1:] != 0).sum().item()) == 0                    # windows that reach into the separator
+        # (the last window of a record reaches into the '\n': for k = 23 it is answered like any query with a foreign byte — the
+        # reverse-complement probe of its sanitised code may hit, python_wrapper.cpp:610-627 — so it is not asserted to be 0)
         rows = seqs.view(n_seq, L + 1)
         for sidx in (0, 1, 4_999, 50_000, 99_999):
-            win = rows[sidx, :L].unfold(0, k, 1).contiguous().view(-1)               # every window of the sequence, as a query batch
+            win = rows[sidx].unfold(0, k, 1).contiguous().view(-1)                   # every window of the record (incl. the one over the '\n'), as a query batch
             want = index.tf_ascii_t(win)
-            assert torch.equal(prof[sidx, : L - k + 1], want), (k, sidx)
+            assert torch.equal(prof[sidx], want), (k, sidx)
         if k == 23:
             assert float((prof[:, : L - k + 1] != 0).float().mean().item()) > 0.9    # genome reads: nearly every window is a key
         del prof, seqs
