@@ -88,6 +88,7 @@ SIGNATURES = {
     "aix_positions_fill_dev": (i32, [vp, vp, u64, u64, vp, vp, u64, vp]),
     "aix_positions_bucket_counts": (i32, [vp, vp, u64, i32, vp]),
     "aix_positions_start": (i32, [vp, u64, C.POINTER(u64)]),
+    "aix_positions_start_k": (i32, [vp, u64, i32, C.POINTER(u64)]),
     "aix_positions_fill_shard": (i32, [vp, vp, u64, i32, u64, vp, vp, u64]),
     "aix_window_codes_dev": (i32, [vp, u64, i32, i32, vp, vp]),
     "aix_normalize_reads": (i32, [vp, u64, i32, i32, vp, C.POINTER(u64)]),

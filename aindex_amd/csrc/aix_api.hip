@@ -115,6 +115,7 @@ struct aix_index {
         d.n = n;
         d.tf13_code = tf13_code;
         d.tf13_mphf = tf13_mphf;
+        d.perm13 = perm13;
         d.canonical_only = (canonical_only && canonical_fastpath) ? 1u : 0u;
         d.k = k;
         d.use_fp = (has_fp && fp_filter) ? 1u : 0u;
@@ -640,7 +641,7 @@ static int lookup_ascii_dev(aix_index_t* h, const char* d_kmers, uint64_t N, int
         }
         HIPCHK(launch_lookup23_ascii(d, (const uint8_t*)d_kmers, N, mode, o, (hipStream_t)stream));
     } else {
-        if (mode == MODE_HASH || mode == MODE_KIDSTRAND) return AIX_ERR_MODE;   // hash_map is null in 13-mer mode
+        if (mode == MODE_KIDSTRAND) return AIX_ERR_MODE;       // hash_map is null in 13-mer mode (kid / strand need the checker)
         HIPCHK(launch_lookup13_ascii(d, (const uint8_t*)d_kmers, N, mode, o, (hipStream_t)stream));
     }
     return AIX_OK;
@@ -1076,7 +1077,6 @@ extern "C" int aix_tf_batch_ascii(aix_index_t* h, const char* kmers, uint64_t N,
 }
 extern "C" int aix_hash_batch_ascii(aix_index_t* h, const char* kmers, uint64_t N, uint64_t* out) {
     if (N && !out) return AIX_ERR_ARG;
-    if (h && h->k != 23) return AIX_ERR_MODE;
     if (empty23(h)) return AIX_ERR_UNSUPPORTED;
     uint32_t eb[3] = {8, 0, 0};
     void* outs[3] = {out, nullptr, nullptr};
@@ -1335,8 +1335,7 @@ extern "C" int aix_count23_fixed(aix_index_t* h, const char* buf, uint64_t len, 
 // ---------------------------------------------------------------------------------------------
 // first window the reference's single worker looks at (hash.cpp:973-986): the start is pushed past any
 // '\n', '~' or '?' found in the first k bytes, repeatedly
-static uint64_t a2_start(const char* c, uint64_t len) {
-    const uint64_t k = 23;
+static uint64_t a2_start(const char* c, uint64_t len, uint64_t k = 23) {
     if (len < k) return 0;
     uint64_t start = 0;
     const uint64_t end = len;
@@ -1352,7 +1351,6 @@ static uint64_t a2_start(const char* c, uint64_t len) {
 extern "C" int aix_positions_fill(aix_index_t* h, const char* reads, uint64_t len, uint64_t* indices_out, uint64_t* positions_out, uint64_t positions_cap,
                                   uint64_t* total_out) {
     if (!h || !indices_out || (len && !reads)) return AIX_ERR_ARG;
-    if (h->k != 23) return AIX_ERR_MODE;
     DevGuard g(h->device);
     const uint64_t n = h->n;
     uint64_t piece = 0;                                                        // 0: default (2^30 windows per sort)
@@ -1372,7 +1370,7 @@ extern "C" int aix_positions_fill(aix_index_t* h, const char* reads, uint64_t le
     HIPCHK(dpos.alloc(8 * total));
     if (len) HIPCHK(hipMemcpy(dreads.p, reads, len, hipMemcpyHostToDevice));
     HIPCHK(hipMemset(dpos.p, 0, 8 * total));
-    HIPCHK(positions_fill(h->dev(), (const uint8_t*)dreads.p, len, a2_start(reads, len), (const uint64_t*)dind.p, (uint64_t*)dpos.p, piece, nullptr, 0, 0));
+    HIPCHK(positions_fill(h->dev(), (const uint8_t*)dreads.p, len, a2_start(reads, len, h->k), (const uint64_t*)dind.p, (uint64_t*)dpos.p, piece, nullptr, 0, 0));
     HIPCHK(hipMemcpy(positions_out, dpos.p, 8 * total, hipMemcpyDeviceToHost));
     return AIX_OK;
 }
@@ -1381,7 +1379,6 @@ extern "C" int aix_positions_fill(aix_index_t* h, const char* reads, uint64_t le
 // aix_positions_total) written in HBM. `start` = aix_positions_start of the buffer's head (the caller holds the bytes).
 extern "C" int aix_positions_total(aix_index_t* h, uint64_t* total_out) {
     if (!h || !total_out) return AIX_ERR_ARG;
-    if (h->k != 23) return AIX_ERR_MODE;
     DevGuard g(h->device);
     *total_out = 0;
     if (h->n == 0) return AIX_OK;
@@ -1395,7 +1392,6 @@ extern "C" int aix_positions_total(aix_index_t* h, uint64_t* total_out) {
 extern "C" int aix_positions_fill_dev(aix_index_t* h, const char* d_reads, uint64_t len, uint64_t start, uint64_t* d_indices_out, uint64_t* d_positions_out,
                                       uint64_t positions_cap, void* stream) {
     if (!h || !d_indices_out || (len && !d_reads)) return AIX_ERR_ARG;
-    if (h->k != 23) return AIX_ERR_MODE;
     DevGuard g(h->device);
     hipStream_t s = (hipStream_t)stream;
     const uint64_t n = h->n;
@@ -1419,11 +1415,15 @@ extern "C" int aix_positions_start(const char* reads, uint64_t len, uint64_t* st
     *start_out = a2_start(reads, len);
     return AIX_OK;
 }
+extern "C" int aix_positions_start_k(const char* reads, uint64_t len, int k, uint64_t* start_out) {
+    if (!start_out || (len && !reads) || (k != 13 && k != 23)) return AIX_ERR_ARG;
+    *start_out = a2_start(reads, len, (uint64_t)k);
+    return AIX_OK;
+}
 
 // A2 over shards of the reads file (multi-GPU): tally, then fill with the counters of the earlier shards
 extern "C" int aix_positions_bucket_counts(aix_index_t* h, const char* reads, uint64_t len, int first_shard, uint64_t* counts_out) {
     if (!h || !counts_out || (len && !reads)) return AIX_ERR_ARG;
-    if (h->k != 23) return AIX_ERR_MODE;
     DevGuard g(h->device);
     const uint64_t n = h->n;
     if (n == 0) return AIX_OK;
@@ -1432,7 +1432,7 @@ extern "C" int aix_positions_bucket_counts(aix_index_t* h, const char* reads, ui
     HIPCHK(dcnt.alloc(8 * n));
     if (len) HIPCHK(hipMemcpy(dreads.p, reads, len, hipMemcpyHostToDevice));
     HIPCHK(hipMemset(dcnt.p, 0, 8 * n));
-    HIPCHK(positions_bucket_counts(h->dev(), (const uint8_t*)dreads.p, len, first_shard ? a2_start(reads, len) : 0, (unsigned long long*)dcnt.p, 0));
+    HIPCHK(positions_bucket_counts(h->dev(), (const uint8_t*)dreads.p, len, first_shard ? a2_start(reads, len, h->k) : 0, (unsigned long long*)dcnt.p, 0));
     HIPCHK(hipMemcpy(counts_out, dcnt.p, 8 * n, hipMemcpyDeviceToHost));
     return AIX_OK;
 }
@@ -1440,7 +1440,6 @@ extern "C" int aix_positions_bucket_counts(aix_index_t* h, const char* reads, ui
 extern "C" int aix_positions_fill_shard(aix_index_t* h, const char* reads, uint64_t len, int first_shard, uint64_t base_offset, const uint32_t* filled_init,
                                         uint64_t* positions_out, uint64_t positions_cap) {
     if (!h || !positions_out || (len && !reads)) return AIX_ERR_ARG;
-    if (h->k != 23) return AIX_ERR_MODE;
     DevGuard g(h->device);
     const uint64_t n = h->n;
     if (n == 0) return AIX_OK;
@@ -1461,7 +1460,7 @@ extern "C" int aix_positions_fill_shard(aix_index_t* h, const char* reads, uint6
     }
     if (len) HIPCHK(hipMemcpy(dreads.p, reads, len, hipMemcpyHostToDevice));
     HIPCHK(hipMemset(dpos.p, 0, 8 * total));
-    HIPCHK(positions_fill(h->dev(), (const uint8_t*)dreads.p, len, first_shard ? a2_start(reads, len) : 0, (const uint64_t*)dind.p, (uint64_t*)dpos.p, piece,
+    HIPCHK(positions_fill(h->dev(), (const uint8_t*)dreads.p, len, first_shard ? a2_start(reads, len, h->k) : 0, (const uint64_t*)dind.p, (uint64_t*)dpos.p, piece,
                           filled_init ? (const uint32_t*)dfill.p : nullptr, base_offset, 0));
     HIPCHK(hipMemcpy(positions_out, dpos.p, 8 * total, hipMemcpyDeviceToHost));
     return AIX_OK;

@@ -14,6 +14,7 @@ struct IndexDev {
     uint64_t n;               // 23-mer: number of keys; 13-mer: 4^13
     const uint64_t* tf13_code;  // 13-mer: tf in 2-bit-code order (u64[4^13])
     const uint64_t* tf13_mphf;  // 13-mer: tf in mphf order (the file's order)
+    const uint32_t* perm13;     // 13-mer: 2-bit code -> mphf slot
     uint32_t canonical_only;  // 23-mer: every stored code <= its reverse complement
     uint32_t k;
     uint32_t use_fp;          // 23-mer: the fingerprint nibbles of the MPHF records are populated
@@ -88,6 +89,11 @@ hipError_t positions_bucket_counts(const IndexDev& ix, const uint8_t* d_reads, u
 // distinct k-mers = sort + run-length of window codes; outputs hipMalloc'd (caller frees), d_codes is clobbered
 hipError_t distinct_from_codes(uint64_t* d_codes, uint64_t nwin, int k, uint64_t min_count, uint64_t** d_keys_out, uint32_t** d_counts_out, uint64_t* n_out,
                                hipStream_t s);
+// the same without a full-width sort (aix_k1.hip): MSD partition in two levels + per-bucket LDS hash / sort. d_codes is clobbered.
+// *fell_back: a bucket held too many distinct remainders; nothing was produced and the caller takes the radix-sort path.
+bool k1_msd_eligible(uint64_t nwin, int k);
+hipError_t distinct_from_codes_msd(uint64_t* d_codes, uint64_t nwin, int k, uint64_t** d_keys_out, uint32_t** d_counts_out, uint64_t* n_out, bool* fell_back,
+                                   hipStream_t s);
 hipError_t distinct_from_plain(const uint8_t* d_plain, uint64_t plen, int k, int canon_mode, uint64_t min_count, uint64_t piece, uint64_t** d_keys_out,
                                uint64_t** d_counts_out, uint64_t* n_out, hipStream_t s);
 hipError_t merge_counts(const uint64_t* d_keys, const uint64_t* d_counts, uint64_t n, uint64_t min_count, uint64_t** d_keys_out, uint64_t** d_counts_out,

@@ -1,0 +1,490 @@
+// aix_k1.hip — K1 row (kmer_counter: count_kmers.cpp:297-341, distinct canonical k-mers with their counts) without a
+// full-width library sort. The window codes (k_window_codes, 2k <= 46 bits) are partitioned most-significant-digit first
+// in two levels, and every final bucket is counted and ordered inside LDS:
+//
+//   k_k1_split    level 1: 16 384-code tiles are counting-sorted in LDS by the top 11 bits (rank = one returning LDS atomic
+//                 per code) and each partition's run is appended to the workgroup's current 128-entry chunk of that partition
+//                 (chunk ids from a per-workgroup region, as in aix_count13.hip: nothing is sized beforehand)
+//   directory     (partition, fill) of every chunk, sorted by partition (a few 10^5 u16 keys)
+//   k_k1_count    level 2, pass 1: one workgroup per level-1 partition histograms the next D2 bits -> bucket sizes
+//   scan          bucket sizes -> bucket bases (exact: level 2 writes contiguous buckets, no chunk lists)
+//   k_k1_scatter  level 2, pass 2: the partition's chunks are tile-sorted in LDS by those D2 bits and written out as runs of
+//                 32-bit remainders at the bucket bases
+//   k_k1_final    one workgroup per bucket (~10^3 codes): open-addressing hash table in LDS (a k-mer that occurs 10^5 times is
+//                 ONE slot and 10^5 LDS adds — heavy hitters cost no capacity), distinct keys compacted and bitonic-sorted in
+//                 LDS, (key, count) written at the bucket base
+//   k_k1_gather   buckets closed up into the final arrays (bucket order = key order)
+//
+// D2 is chosen so that a bucket holds ~10^3 codes. A bucket with more than K1_DMAX distinct remainders (possible only when
+// the codes are far from uniform in their top 11 + D2 bits) raises a flag and the caller falls back to the radix-sort path:
+// the result never depends on which path ran.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "aix_internal.hpp"
+
+namespace aix {
+
+static constexpr int K1_PBITS = 11;
+static constexpr int K1_P = 1 << K1_PBITS;            // level-1 partitions
+static constexpr int K1_TB = 1024;                    // threads of the split / count / scatter workgroups
+static constexpr int K1_WPT = 16;                     // codes per lane and tile
+static constexpr int K1_TILE = K1_TB * K1_WPT;        // 16384 codes per tile (128 KiB of u64 in LDS)
+static constexpr int K1_CH = 128;                     // entries per chunk (1 KiB)
+static constexpr int K1_FILLBITS = 8;                 // cursor = (chunk << 8) | fill, fill in [0, 128]
+static constexpr int K1_DUMMY = 64;
+static constexpr unsigned K1_MAXGRID = 512;
+static constexpr int K1_FB = 256;                     // threads of the per-bucket workgroup
+static constexpr int K1_CAP = 4096;                   // hash slots per bucket
+static constexpr int K1_DMAX = 2048;                  // distinct remainders a bucket may hold
+static constexpr uint64_t K1_INVALID = ~0ull;
+
+// ---------------------------------------------------------------------------------------------
+// the tile counting sort shared by the two levels: P = 2048 counters, two per lane
+// ---------------------------------------------------------------------------------------------
+struct TileLds {
+    uint32_t* hist;      // [P + DUMMY] tile-local count per digit; level 1 re-uses it for the first NEW chunk of the partition
+    uint32_t* loc_off;   // [P] exclusive scan of hist
+    uint32_t* cursor;    // [P] level 1: (current chunk << 8) | fill; level 2: running position inside the bucket
+    uint32_t* wsum;      // [16]
+    uint64_t* sorted;    // [TILE]
+};
+__device__ __forceinline__ TileLds tile_lds(uint8_t* smem) {
+    TileLds l;
+    l.hist = (uint32_t*)smem;
+    l.loc_off = l.hist + K1_P + K1_DUMMY;
+    l.cursor = l.loc_off + K1_P;
+    l.wsum = l.cursor + K1_P;
+    l.sorted = (uint64_t*)(l.wsum + 16);
+    return l;
+}
+static constexpr size_t K1_TILE_LDS = 4 * (3 * K1_P + K1_DUMMY + 16) + 8 * (size_t)K1_TILE;   // 155 968 B
+
+// block-wide exclusive scan of one 32-bit value per lane (1024 lanes); `all` = the total. Two barriers.
+__device__ __forceinline__ uint32_t block_scan_excl(uint32_t mine, uint32_t* wsum, uint32_t& all) {
+    const int t = threadIdx.x;
+    uint32_t s = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(s, d);
+        if ((t & 63) >= d) s += y;
+    }
+    if ((t & 63) == 63) wsum[t >> 6] = s;
+    __syncthreads();
+    uint32_t off = 0;
+    all = 0;
+    for (int w = 0; w < K1_TB / 64; ++w) {
+        const uint32_t x = wsum[w];
+        if (w < (t >> 6)) off += x;
+        all += x;
+    }
+    __syncthreads();
+    return off + s - mine;
+}
+
+// ---------------------------------------------------------------------------------------------
+// level 1
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(K1_TB) k_k1_split(const uint64_t* __restrict__ codes, uint64_t n, uint32_t s1, uint64_t ntiles, uint32_t region,
+                                                   uint16_t* __restrict__ dir_part, uint16_t* __restrict__ dir_cnt, uint64_t* __restrict__ parts,
+                                                   uint32_t* __restrict__ err) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const TileLds L = tile_lds(smem);
+    const int t = threadIdx.x;
+    constexpr uint32_t FILLMASK = (1u << K1_FILLBITS) - 1;
+    const uint32_t region_base = blockIdx.x * region;
+    uint32_t next_chunk = 0;                                    // same value in every lane
+    L.cursor[2 * t] = K1_CH;
+    L.cursor[2 * t + 1] = K1_CH;
+    L.hist[2 * t] = 0;
+    L.hist[2 * t + 1] = 0;
+    if (t < K1_DUMMY) L.hist[K1_P + t] = 0;
+    __syncthreads();
+    for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        uint64_t c[K1_WPT];
+        uint32_t rank[K1_WPT / 2];
+        const uint64_t base = tile * K1_TILE + (uint64_t)t;     // code j of this lane = base + j * 1024: coalesced 8 KiB per load instruction
+        const uint32_t dummy = K1_P + (t & (K1_DUMMY - 1));
+#pragma unroll
+        for (int j = 0; j < K1_WPT; ++j) {
+            const uint64_t i = base + (uint64_t)j * K1_TB;
+            c[j] = i < n ? codes[i] : K1_INVALID;
+        }
+#pragma unroll
+        for (int j = 0; j < K1_WPT; ++j) {
+            const bool ok = c[j] != K1_INVALID;
+            const uint32_t r = atomicAdd(&L.hist[ok ? (uint32_t)(c[j] >> s1) : dummy], 1u);
+            if (j & 1) rank[j >> 1] |= r << 16; else rank[j >> 1] = r;
+        }
+        __syncthreads();
+        // this lane owns partitions 2t and 2t+1: entries a, b; fresh chunks k0, k1 = by how much they overflow the current chunk
+        const uint32_t a = L.hist[2 * t], b = L.hist[2 * t + 1];
+        const uint32_t c0 = L.cursor[2 * t], c1 = L.cursor[2 * t + 1];
+        const uint32_t tot0 = (c0 & FILLMASK) + a, tot1 = (c1 & FILLMASK) + b;
+        const uint32_t k0 = tot0 > (uint32_t)K1_CH ? (tot0 - 1) / K1_CH : 0u;
+        const uint32_t k1 = tot1 > (uint32_t)K1_CH ? (tot1 - 1) / K1_CH : 0u;
+        uint32_t all;
+        const uint32_t excl = block_scan_excl((a + b) | ((k0 + k1) << 16), L.wsum, all);   // entries <= 16384 and fresh chunks <= 2176 per tile: one scan
+        const uint32_t e0 = excl & 0xFFFFu, nb0 = next_chunk + (excl >> 16), nb1 = nb0 + k0;
+        L.loc_off[2 * t] = e0;
+        L.loc_off[2 * t + 1] = e0 + a;
+        L.hist[2 * t] = nb0;
+        L.hist[2 * t + 1] = nb1;
+        for (uint32_t i = 0; i < k0; ++i) { if (nb0 + i < region) dir_part[region_base + nb0 + i] = (uint16_t)(2 * t); else *err = 1u; }
+        for (uint32_t i = 0; i < k1; ++i) { if (nb1 + i < region) dir_part[region_base + nb1 + i] = (uint16_t)(2 * t + 1); else *err = 1u; }
+        const uint32_t entries = all & 0xFFFFu;
+        next_chunk += all >> 16;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < K1_WPT; ++j) {
+            if (c[j] != K1_INVALID) {
+                const uint32_t r = (j & 1) ? (rank[j >> 1] >> 16) : (rank[j >> 1] & 0xFFFFu);
+                L.sorted[L.loc_off[(uint32_t)(c[j] >> s1)] + r] = c[j];
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = t; i < entries; i += K1_TB) {
+            const uint64_t e = L.sorted[i];
+            const uint32_t p = (uint32_t)(e >> s1);
+            const uint32_t cu = L.cursor[p];
+            const uint32_t pos = (cu & FILLMASK) + (i - L.loc_off[p]);
+            uint32_t chunk, o;
+            if (pos < (uint32_t)K1_CH) { chunk = cu >> K1_FILLBITS; o = pos; }
+            else { chunk = L.hist[p] + (pos - K1_CH) / K1_CH; o = (pos - K1_CH) % K1_CH; }
+            if (chunk < region) parts[(uint64_t)(region_base + chunk) * K1_CH + o] = e; else *err = 1u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {                            // advance the two cursors this lane owns
+            const uint32_t p = 2 * t + q, cu = L.cursor[p], tot = (cu & FILLMASK) + (q ? b : a);
+            if (tot > (uint32_t)K1_CH) {
+                const uint32_t k = (tot - 1) / K1_CH;
+                L.cursor[p] = ((L.hist[p] + k - 1) << K1_FILLBITS) | (tot - k * K1_CH);
+            } else {
+                L.cursor[p] = (cu & ~FILLMASK) | tot;
+            }
+            L.hist[p] = 0;
+        }
+        if (t < K1_DUMMY) L.hist[K1_P + t] = 0;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {                                // the chunk each (workgroup, partition) pair was still filling
+        const uint32_t cu = L.cursor[2 * t + q], fill = cu & FILLMASK, chunk = cu >> K1_FILLBITS;
+        if (fill < (uint32_t)K1_CH) { if (chunk < region) dir_cnt[region_base + chunk] = (uint16_t)fill; else *err = 1u; }
+    }
+}
+
+// chunk range [lo, hi) of partition p in the directory sorted by partition
+__device__ __forceinline__ void partition_range(const uint16_t* __restrict__ spart, uint32_t cap, uint32_t p, uint32_t* range /* LDS[2] */) {
+    if (threadIdx.x < 2) {
+        const uint32_t key = p + threadIdx.x;
+        uint32_t lo = 0, hi = cap;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (spart[mid] < key) lo = mid + 1; else hi = mid; }
+        range[threadIdx.x] = lo;
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------
+// level 2, pass 1: bucket sizes of one level-1 partition per workgroup
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(K1_TB) k_k1_count(const uint64_t* __restrict__ parts, const uint16_t* __restrict__ spart, const uint64_t* __restrict__ sdesc, uint32_t cap,
+                                                   uint32_t s2, uint32_t nb2, uint32_t* __restrict__ bucket_cnt) {
+    __shared__ uint32_t h2[K1_P];
+    __shared__ uint32_t range[2];
+    const uint32_t p = blockIdx.x, t = threadIdx.x;
+    h2[2 * t] = 0;
+    h2[2 * t + 1] = 0;
+    partition_range(spart, cap, p, range);
+    const uint32_t lo = range[0], hi = range[1], dmask = nb2 - 1;
+    // 8 chunks per pass of the workgroup: 128 lanes per chunk, one entry each
+    for (uint32_t c0 = lo; c0 < hi; c0 += K1_TB / K1_CH) {
+        const uint32_t ci = c0 + (t >> 7);
+        if (ci < hi) {
+            const uint64_t desc = sdesc[ci];
+            const uint32_t id = (uint32_t)desc, fill = (uint32_t)(desc >> 32), o = t & (K1_CH - 1);
+            if (o < fill) atomicAdd(&h2[(uint32_t)(parts[(uint64_t)id * K1_CH + o] >> s2) & dmask], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t d = t; d < nb2; d += K1_TB) bucket_cnt[(uint64_t)p * nb2 + d] = h2[d];
+}
+
+// ---------------------------------------------------------------------------------------------
+// level 2, pass 2: tile sort by the D2 bits, runs written at the bucket bases as 32-bit remainders
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(K1_TB) k_k1_scatter(const uint64_t* __restrict__ parts, const uint16_t* __restrict__ spart, const uint64_t* __restrict__ sdesc, uint32_t cap,
+                                                     uint32_t s2, uint32_t nb2, const uint32_t* __restrict__ bucket_base, uint32_t* __restrict__ out32) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ uint32_t range[2];
+    const TileLds L = tile_lds(smem);
+    const uint32_t p = blockIdx.x, t = threadIdx.x;
+    const uint32_t dmask = nb2 - 1;
+    const uint64_t remmask = (1ull << s2) - 1;
+    for (uint32_t d = t; d < (uint32_t)K1_P; d += K1_TB) {
+        L.cursor[d] = d < nb2 ? bucket_base[(uint64_t)p * nb2 + d] : 0u;
+        L.hist[d] = 0;
+    }
+    if (t < (uint32_t)K1_DUMMY) L.hist[K1_P + t] = 0;
+    partition_range(spart, cap, p, range);
+    const uint32_t lo = range[0], hi = range[1];
+    const uint32_t dummy = K1_P + (t & (K1_DUMMY - 1));
+    for (uint32_t c0 = lo; c0 < hi; c0 += K1_TILE / K1_CH) {      // a tile = up to 128 chunks of the partition
+        uint64_t c[K1_WPT];
+        uint32_t rank[K1_WPT / 2];
+#pragma unroll
+        for (int j = 0; j < K1_WPT; ++j) {                        // code j of this lane: chunk c0 + 8 j + t / 128, entry t % 128
+            const uint32_t ci = c0 + 8u * j + (t >> 7);
+            c[j] = K1_INVALID;
+            if (ci < hi) {
+                const uint64_t desc = sdesc[ci];
+                const uint32_t id = (uint32_t)desc, fill = (uint32_t)(desc >> 32), o = t & (K1_CH - 1);
+                if (o < fill) c[j] = parts[(uint64_t)id * K1_CH + o];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < K1_WPT; ++j) {
+            const bool ok = c[j] != K1_INVALID;
+            const uint32_t r = atomicAdd(&L.hist[ok ? ((uint32_t)(c[j] >> s2) & dmask) : dummy], 1u);
+            if (j & 1) rank[j >> 1] |= r << 16; else rank[j >> 1] = r;
+        }
+        __syncthreads();
+        const uint32_t a = L.hist[2 * t], b = L.hist[2 * t + 1];
+        uint32_t all;
+        const uint32_t excl = block_scan_excl(a + b, L.wsum, all);
+        L.loc_off[2 * t] = excl;
+        L.loc_off[2 * t + 1] = excl + a;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < K1_WPT; ++j) {
+            if (c[j] != K1_INVALID) {
+                const uint32_t r = (j & 1) ? (rank[j >> 1] >> 16) : (rank[j >> 1] & 0xFFFFu);
+                L.sorted[L.loc_off[(uint32_t)(c[j] >> s2) & dmask] + r] = c[j];
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = t; i < all; i += K1_TB) {
+            const uint64_t e = L.sorted[i];
+            const uint32_t d = (uint32_t)(e >> s2) & dmask;
+            out32[L.cursor[d] + (i - L.loc_off[d])] = (uint32_t)(e & remmask);
+        }
+        __syncthreads();
+        L.cursor[2 * t] += a;
+        L.cursor[2 * t + 1] += b;
+        L.hist[2 * t] = 0;
+        L.hist[2 * t + 1] = 0;
+        if (t < (uint32_t)K1_DUMMY) L.hist[K1_P + t] = 0;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// per bucket: hash aggregation + sort of the distinct remainders, all in LDS
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(K1_FB) k_k1_final(const uint32_t* __restrict__ in32, const uint32_t* __restrict__ bucket_base, uint32_t nbuckets, uint32_t s2,
+                                                   uint64_t* __restrict__ keys_out, uint32_t* __restrict__ cnt_out, uint32_t* __restrict__ distinct_m,
+                                                   uint32_t* __restrict__ overflow) {
+    __shared__ uint32_t hk[K1_CAP];          // remainder + 1 (0 = empty)
+    __shared__ uint32_t hc[K1_CAP];
+    __shared__ uint32_t dk[K1_DMAX];
+    __shared__ uint32_t dc[K1_DMAX];
+    __shared__ uint32_t ndist, m_out;
+    const uint32_t t = threadIdx.x;
+    for (uint32_t b = blockIdx.x; b < nbuckets; b += gridDim.x) {
+        const uint32_t lo = bucket_base[b], n_e = bucket_base[b + 1] - lo;
+        if (n_e == 0) { if (t == 0) distinct_m[b] = 0; continue; }
+        // table size: a power of two >= 2 x (the most distinct remainders this bucket can be allowed to hold)
+        uint32_t cap = 64;
+        const uint32_t want = 2u * min(n_e, (uint32_t)K1_DMAX);
+        while (cap < want) cap <<= 1;
+        for (uint32_t i = t; i < cap; i += K1_FB) { hk[i] = 0; hc[i] = 0; }
+        if (t == 0) { ndist = 0; m_out = 0; }
+        __syncthreads();
+        for (uint32_t i = t; i < n_e; i += K1_FB) {
+            const uint32_t key = in32[lo + i] + 1u;              // remainders are < 2^31 (s2 <= 31): + 1 cannot wrap to the empty marker
+            uint32_t h = (key * 0x9E3779B1u) >> 7;
+            for (uint32_t probes = 0; probes < cap; ++probes) {
+                h &= cap - 1;
+                const uint32_t old = atomicCAS(&hk[h], 0u, key);
+                if (old == 0u) atomicAdd(&ndist, 1u);
+                if (old == 0u || old == key) { atomicAdd(&hc[h], 1u); break; }
+                ++h;
+            }
+        }
+        __syncthreads();
+        const uint32_t nd = ndist;
+        if (nd > (uint32_t)K1_DMAX) {                            // too many distinct remainders for the LDS arrays (or a full table dropped some)
+            if (t == 0) { *overflow = 1u; distinct_m[b] = 0; }
+            __syncthreads();
+            continue;
+        }
+        for (uint32_t i = t; i < cap; i += K1_FB) {
+            const uint32_t k = hk[i];
+            if (k) { const uint32_t idx = atomicAdd(&m_out, 1u); dk[idx] = k - 1u; dc[idx] = hc[i]; }
+        }
+        __syncthreads();
+        const uint32_t m = m_out;
+        uint32_t mp = 1;
+        while (mp < m) mp <<= 1;
+        for (uint32_t i = m + t; i < mp; i += K1_FB) { dk[i] = 0xFFFFFFFFu; dc[i] = 0; }
+        __syncthreads();
+        for (uint32_t k = 2; k <= mp; k <<= 1) {                 // bitonic sort of (dk, dc) by dk, ascending
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t i = t; i < mp; i += K1_FB) {
+                    const uint32_t x = i ^ j;
+                    if (x > i) {
+                        const uint32_t ka = dk[i], kb = dk[x];
+                        const bool up = (i & k) == 0;
+                        if ((ka > kb) == up) {
+                            dk[i] = kb; dk[x] = ka;
+                            const uint32_t ca = dc[i]; dc[i] = dc[x]; dc[x] = ca;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        const uint64_t prefix = (uint64_t)b << s2;               // bucket id = the top 11 + D2 bits of the code
+        for (uint32_t i = t; i < m; i += K1_FB) {
+            keys_out[lo + i] = prefix | dk[i];
+            cnt_out[lo + i] = dc[i];
+        }
+        if (t == 0) distinct_m[b] = m;
+        __syncthreads();
+    }
+}
+
+// buckets closed up: bucket b's m entries move from its base to dm_off[b]; one wave per bucket
+__global__ void __launch_bounds__(256) k_k1_gather(const uint64_t* __restrict__ keys_st, const uint32_t* __restrict__ cnt_st, const uint32_t* __restrict__ bucket_base,
+                                                  const uint32_t* __restrict__ dm_off, uint32_t nbuckets, uint64_t* __restrict__ keys, uint32_t* __restrict__ counts) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t nw = (uint64_t)gridDim.x * 4;
+    for (uint64_t b = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); b < nbuckets; b += nw) {
+        const uint32_t src = bucket_base[b], dst = dm_off[b], m = dm_off[b + 1] - dst;
+        for (uint32_t i = lane; i < m; i += 64) { keys[dst + i] = keys_st[src + i]; counts[dst + i] = cnt_st[src + i]; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static inline uint64_t up256(uint64_t x) { return (x + 255) / 256 * 256; }
+struct K1Desc {
+    const uint16_t* dir_cnt;
+    __host__ __device__ uint64_t operator()(uint32_t i) const { return (uint64_t)i | ((uint64_t)dir_cnt[i] << 32); }
+};
+
+bool k1_msd_eligible(uint64_t nwin, int k) {
+    if (getenv("AIX_K1_ROCPRIM") != nullptr) return false;      // A/B switch: the radix-sort path
+    return k >= 9 && k <= 23 && nwin > 0 && nwin <= (1ull << 31);
+}
+
+// d_codes: nwin window codes (~0 = no k-mer), clobbered (re-used as staging). Outputs are pool blocks (caller releases).
+// *fell_back = true: a bucket overflowed, nothing was produced (the caller runs the radix-sort path on d_codes — intact in that case
+// only if it re-creates the codes, so the caller keeps a way to regenerate them).
+hipError_t distinct_from_codes_msd(uint64_t* d_codes, uint64_t nwin, int k, uint64_t** d_keys_out, uint32_t** d_counts_out, uint64_t* n_out, bool* fell_back,
+                                   hipStream_t s) {
+    *d_keys_out = nullptr; *d_counts_out = nullptr; *n_out = 0; *fell_back = false;
+    const uint32_t B = 2u * (uint32_t)k, s1 = B - K1_PBITS;
+    // D2: ~768 codes per bucket on average; the remainder must fit 32 bits
+    uint32_t D2 = 3;
+    while (D2 < 11 && (nwin >> (K1_PBITS + D2)) > 768) ++D2;
+    while (s1 - D2 > 31) ++D2;                                  // remainder + 1 must not wrap (0 marks an empty hash slot)
+    if (D2 > s1) D2 = s1;
+    const uint32_t s2 = s1 - D2, nb2 = 1u << D2;
+    const uint32_t nbuckets = (uint32_t)K1_P * nb2;
+    const uint64_t ntiles = (nwin + K1_TILE - 1) / K1_TILE;
+    const unsigned grid = (unsigned)std::min<uint64_t>(ntiles, K1_MAXGRID);
+    uint32_t region = (uint32_t)((ntiles + grid - 1) / grid * (K1_TILE / K1_CH) + K1_P);
+    if (const char* e = getenv("AIX_K1_TEST_REGION")) { const long v = atol(e); if (v > 0) region = (uint32_t)v; }   // test hook: an undersized region must fail loudly
+    const uint32_t cap = grid * region;
+    // one block: err | overflow | dir_part | dir_cnt | spart | sdesc | sort temp | bucket_cnt (nbuckets + 1) | bucket_base | distinct_m | dm_off | out32 | parts
+    size_t sort_tmp = 0;
+    {
+        auto vals = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), K1Desc{nullptr});
+        (void)rocprim::radix_sort_pairs(nullptr, sort_tmp, (const uint16_t*)nullptr, (uint16_t*)nullptr, vals, (uint64_t*)nullptr, (size_t)cap, 0u, 12u, s);
+    }
+    size_t scan_tmp = 0;
+    (void)rocprim::exclusive_scan(nullptr, scan_tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)nbuckets + 1, rocprim::plus<uint32_t>(), s);
+    const uint64_t o_flags = 0, o_dirp = 256, o_dirc = o_dirp + up256(2ull * cap), o_spart = o_dirc + up256(2ull * cap), o_sdesc = o_spart + up256(2ull * cap),
+                   o_stmp = o_sdesc + up256(8ull * cap), o_bcnt = o_stmp + up256(std::max(sort_tmp, scan_tmp)), o_bbase = o_bcnt + up256(4ull * (nbuckets + 1)),
+                   o_dm = o_bbase + up256(4ull * (nbuckets + 1)), o_dmo = o_dm + up256(4ull * (nbuckets + 1)), o_out32 = o_dmo + up256(4ull * (nbuckets + 1)),
+                   o_parts = o_out32 + up256(4ull * nwin), total = o_parts + 8ull * cap * K1_CH;
+    uint8_t* w = nullptr;
+    hipError_t e = pool_alloc((void**)&w, total);
+    if (e != hipSuccess) return e;
+    uint32_t* err = (uint32_t*)(w + o_flags);
+    uint32_t* overflow = err + 1;
+    uint16_t* dir_part = (uint16_t*)(w + o_dirp);
+    uint16_t* dir_cnt = (uint16_t*)(w + o_dirc);
+    uint16_t* spart = (uint16_t*)(w + o_spart);
+    uint64_t* sdesc = (uint64_t*)(w + o_sdesc);
+    void* tmp = w + o_stmp;
+    uint32_t* bucket_cnt = (uint32_t*)(w + o_bcnt);
+    uint32_t* bucket_base = (uint32_t*)(w + o_bbase);
+    uint32_t* distinct_m = (uint32_t*)(w + o_dm);
+    uint32_t* dm_off = (uint32_t*)(w + o_dmo);
+    uint32_t* out32 = (uint32_t*)(w + o_out32);
+    uint64_t* parts = (uint64_t*)(w + o_parts);
+    uint64_t* keys = nullptr;
+    uint32_t* counts = nullptr;
+    uint32_t flags[2] = {0, 0};
+    uint32_t total_distinct = 0;
+    do {
+        e = hipFuncSetAttribute((const void*)k_k1_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K1_TILE_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_k1_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K1_TILE_LDS);
+        if (e == hipSuccess) e = hipMemsetAsync(w, 0, 256, s);
+        if (e == hipSuccess) e = hipMemsetD16Async((hipDeviceptr_t)dir_part, (unsigned short)K1_P, cap, s);      // "no partition": sorts behind every real one
+        if (e == hipSuccess) e = hipMemsetD16Async((hipDeviceptr_t)dir_cnt, (unsigned short)K1_CH, cap, s);      // chunks are full unless the split says otherwise
+        if (e == hipSuccess) e = hipMemsetAsync(bucket_cnt, 0, 4ull * (nbuckets + 1), s);
+        if (e == hipSuccess) e = hipMemsetAsync(distinct_m, 0, 4ull * (nbuckets + 1), s);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(k_k1_split, dim3(grid), dim3(K1_TB), K1_TILE_LDS, s, (const uint64_t*)d_codes, nwin, s1, ntiles, region, dir_part, dir_cnt, parts, err);
+        auto vals = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), K1Desc{dir_cnt});
+        size_t tb = sort_tmp;
+        e = rocprim::radix_sort_pairs(tmp, tb, (const uint16_t*)dir_part, spart, vals, sdesc, (size_t)cap, 0u, 12u, s);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(k_k1_count, dim3(K1_P), dim3(K1_TB), 0, s, (const uint64_t*)parts, (const uint16_t*)spart, (const uint64_t*)sdesc, cap, s2, nb2, bucket_cnt);
+        tb = scan_tmp;
+        e = rocprim::exclusive_scan(tmp, tb, bucket_cnt, bucket_base, 0u, (size_t)nbuckets + 1, rocprim::plus<uint32_t>(), s);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(k_k1_scatter, dim3(K1_P), dim3(K1_TB), K1_TILE_LDS, s, (const uint64_t*)parts, (const uint16_t*)spart, (const uint64_t*)sdesc, cap, s2, nb2,
+                           (const uint32_t*)bucket_base, out32);
+        // staging of the per-bucket results: keys over the (now consumed) code array, counts over the (now consumed) chunk array
+        uint64_t* keys_st = d_codes;
+        uint32_t* cnt_st = (uint32_t*)parts;
+        hipLaunchKernelGGL(k_k1_final, dim3(std::min<uint32_t>(nbuckets, 1u << 20)), dim3(K1_FB), 0, s, (const uint32_t*)out32, (const uint32_t*)bucket_base, nbuckets, s2,
+                           keys_st, cnt_st, distinct_m, overflow);
+        tb = scan_tmp;
+        e = rocprim::exclusive_scan(tmp, tb, distinct_m, dm_off, 0u, (size_t)nbuckets + 1, rocprim::plus<uint32_t>(), s);
+        if (e == hipSuccess) e = hipMemcpyAsync(flags, w, 8, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(&total_distinct, dm_off + nbuckets, 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) break;
+        if (flags[0]) { e = hipErrorAssert; break; }             // chunk region exhausted: never silent (the caller reports it)
+        if (flags[1]) { *fell_back = true; break; }
+        if (total_distinct == 0) break;
+        e = pool_alloc((void**)&keys, 8ull * total_distinct);
+        if (e == hipSuccess) e = pool_alloc((void**)&counts, 4ull * total_distinct);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(k_k1_gather, dim3(std::min<uint32_t>((nbuckets + 3) / 4, 1u << 16)), dim3(256), 0, s, (const uint64_t*)keys_st, (const uint32_t*)cnt_st,
+                           (const uint32_t*)bucket_base, (const uint32_t*)dm_off, nbuckets, keys, counts);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    } while (false);
+    { const hipError_t es = hipStreamSynchronize(s); if (e == hipSuccess) e = es; }
+    pool_free(w);
+    if (e != hipSuccess || *fell_back) {
+        if (keys) pool_free(keys);
+        if (counts) pool_free(counts);
+        return e;
+    }
+    *d_keys_out = keys; *d_counts_out = counts; *n_out = total_distinct;
+    return hipSuccess;
+}
+
+}  // namespace aix

@@ -355,6 +355,11 @@ __global__ void __launch_bounds__(kBlock) k_lookup13_ascii(const IndexDev ix, co
         const Enc13 e = encode13_words(w0, w1);
         if (MODE == MODE_TF) {                                  // get_tf_values_13mer :938-980: strict, u32 truncation
             out.tf[i] = e.valid ? (uint32_t)ix.tf13_code[e.code] : 0u;
+        } else if (MODE == MODE_HASH) {                         // hasher_13mer.lookup(kmer) (:1087): the tabulated slot, or the MPHF of the raw bytes
+            uint64_t hval;
+            if (e.valid) hval = ix.perm13[e.code];
+            else { uint64_t a, b, c; jenkins13(w0, w1, ix.m.seed, a, b, c); hval = mphf_from_hash(ix.m, a, b, c); }
+            out.u64a[i] = hval;
         } else {
             uint64_t f, r;
             if (e.valid) {
@@ -886,6 +891,7 @@ hipError_t launch_lookup13_ascii(const IndexDev& ix, const uint8_t* q, uint64_t 
     if (N == 0) return hipSuccess;
     switch (mode) {
         case MODE_TF: AIX_LAUNCH(k_lookup13_ascii<MODE_TF>, N, s, ix, q, N, out);
+        case MODE_HASH: AIX_LAUNCH(k_lookup13_ascii<MODE_HASH>, N, s, ix, q, N, out);
         case MODE_BOTH: AIX_LAUNCH(k_lookup13_ascii<MODE_BOTH>, N, s, ix, q, N, out);
         case MODE_TOTAL: AIX_LAUNCH(k_lookup13_ascii<MODE_TOTAL>, N, s, ix, q, N, out);
     }

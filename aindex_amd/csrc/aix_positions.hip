@@ -91,12 +91,34 @@ __global__ void __launch_bounds__(kB) k_a2_place(const IndexDev ix, const uint32
                                                 const uint64_t* __restrict__ indices, uint64_t* __restrict__ positions) {
     const uint64_t stride = (uint64_t)gridDim.x * kB;
     const uint32_t n = (uint32_t)ix.n;
+    const bool k13 = ix.k == 13;
     for (uint64_t j = (uint64_t)blockIdx.x * kB + threadIdx.x; j < nwin; j += stride) {
         const uint32_t h = skeys[j];
         if (h >= n) continue;
         const uint64_t rank = (uint64_t)filled[h] + (j - first[h]);
-        if (rank < ix.keys[h].tf) positions[indices[h] + rank] = piece_first + svals[j] + 1;     // :1037-1040, 1-based offsets
+        const uint64_t tf = k13 ? ix.tf13_mphf[h] : (uint64_t)ix.keys[h].tf;                       // 13-mer: the u64 table of count_kmers13
+        if (rank < tf) positions[indices[h] + rank] = piece_first + svals[j] + 1;                // :1037-1040 / compute_aindex13.cpp:205-211, 1-based offsets
     }
+}
+// 13-mer probe (compute_aindex13.cpp:163-204): a window counts iff its 13 bytes are upper-case A/C/G/T; forward strand only;
+// bucket = mphf(window) = perm13[code] (the MPHF over all 13-mers, tabulated at open)
+__global__ void __launch_bounds__(kB) k_a2_probe13(const uint32_t* __restrict__ perm13, const uint8_t* __restrict__ buf, uint64_t nwin, uint64_t start,
+                                                  uint32_t* __restrict__ keys) {
+    const uint64_t stride = (uint64_t)gridDim.x * kB;
+    for (uint64_t i = (uint64_t)blockIdx.x * kB + threadIdx.x; i < nwin; i += stride) {
+        uint32_t key = 67108864u;
+        if (i >= start) {
+            uint64_t w0, w1;
+            load13(buf + i, w0, w1);
+            const Enc13 e = encode13_words(w0, w1);
+            if (e.valid) { const uint32_t h = perm13[e.code]; if (h < 67108864u) key = h; }
+        }
+        keys[i] = key;
+    }
+}
+__global__ void __launch_bounds__(kB) k_tf13_copy(const uint64_t* __restrict__ tf, uint64_t n, uint64_t* __restrict__ out) {
+    const uint64_t stride = (uint64_t)gridDim.x * kB;
+    for (uint64_t i = (uint64_t)blockIdx.x * kB + threadIdx.x; i <= n; i += stride) out[i] = i < n ? tf[i] : 0ull;
 }
 // after a piece has been placed: filled[h] += occurrences of h in the piece (saturating; tf is 32 bits, so a saturated
 // counter can never admit another offset). One writer per bucket: the lane that holds the last element of h's run.
@@ -120,13 +142,19 @@ __global__ void __launch_bounds__(kB) k_a2_tally(const uint32_t* __restrict__ ke
     }
 }
 
+static void launch_a2_probe(const IndexDev& ix, const uint8_t* d_reads, uint64_t nwin, uint64_t start, uint32_t* keys, hipStream_t s) {
+    if (ix.k == 13) hipLaunchKernelGGL(k_a2_probe13, dim3(grid_of(nwin)), dim3(kB), 0, s, ix.perm13, d_reads, nwin, start, keys);
+    else hipLaunchKernelGGL(k_a2_probe, dim3(grid_of(nwin)), dim3(kB), 0, s, ix, d_reads, nwin, start, keys);
+}
+
 // indices (device, n+1 entries). Returns hip error.
 hipError_t positions_indices(const IndexDev& ix, uint64_t* d_indices, hipStream_t s) {
     const uint64_t n = ix.n;
     uint64_t* tf64 = nullptr;
     hipError_t e = pool_alloc((void**)&tf64, 8 * (n + 1));
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_tf_u64, dim3(grid_of(n + 1)), dim3(kB), 0, s, ix.keys, n, tf64);
+    if (ix.k == 13) hipLaunchKernelGGL(k_tf13_copy, dim3(grid_of(n + 1)), dim3(kB), 0, s, ix.tf13_mphf, n, tf64);   // compute_aindex13.cpp:57-63
+    else hipLaunchKernelGGL(k_tf_u64, dim3(grid_of(n + 1)), dim3(kB), 0, s, ix.keys, n, tf64);
     size_t tmp_bytes = 0;
     e = rocprim::exclusive_scan(nullptr, tmp_bytes, tf64, d_indices, (uint64_t)0, (size_t)(n + 1), rocprim::plus<uint64_t>(), s);
     void* tmp = nullptr;
@@ -143,14 +171,14 @@ hipError_t positions_indices(const IndexDev& ix, uint64_t* d_indices, hipStream_
 // keeps every bucket's offsets ascending (the reference's 1-thread order) for any buffer length.
 // d_counts (device, u64[n], pre-zeroed): how often every bucket occurs in the buffer under A2's window rules
 hipError_t positions_bucket_counts(const IndexDev& ix, const uint8_t* d_reads, uint64_t len, uint64_t start, unsigned long long* d_counts, hipStream_t s) {
-    if (len < 23 || ix.n == 0) return hipSuccess;
-    const uint64_t nwin_all = len - 22;
+    if (len < ix.k || ix.n == 0) return hipSuccess;
+    const uint64_t nwin_all = len - (ix.k - 1);
     const uint64_t pw = std::min<uint64_t>(1ull << 30, nwin_all);
     uint32_t* keys = nullptr;
     hipError_t e = pool_alloc((void**)&keys, 4 * pw);
     for (uint64_t w0 = 0; e == hipSuccess && w0 < nwin_all; w0 += pw) {
         const uint64_t nwin = std::min(pw, nwin_all - w0);
-        hipLaunchKernelGGL(k_a2_probe, dim3(grid_of(nwin)), dim3(kB), 0, s, ix, d_reads + w0, nwin, start > w0 ? start - w0 : 0, keys);
+        launch_a2_probe(ix, d_reads + w0, nwin, start > w0 ? start - w0 : 0, keys, s);
         hipLaunchKernelGGL(k_a2_tally, dim3(grid_of(nwin)), dim3(kB), 0, s, keys, nwin, (uint32_t)ix.n, d_counts);
         e = hipGetLastError();
     }
@@ -163,8 +191,8 @@ hipError_t positions_bucket_counts(const IndexDev& ix, const uint8_t* d_reads, u
 // base_offset: byte offset of this buffer inside the whole reads file (offsets are reported file-relative).
 hipError_t positions_fill(const IndexDev& ix, const uint8_t* d_reads, uint64_t len, uint64_t start, const uint64_t* d_indices, uint64_t* d_positions,
                           uint64_t piece, const uint32_t* filled_init, uint64_t base_offset, hipStream_t s) {
-    if (len < 23 || ix.n == 0) return hipSuccess;
-    const uint64_t nwin_all = len - 22;
+    if (len < ix.k || ix.n == 0) return hipSuccess;
+    const uint64_t nwin_all = len - (ix.k - 1);
     if (piece == 0 || piece > (1ull << 31)) piece = 1ull << 30;
     const uint64_t pw = std::min(piece, nwin_all);
     uint32_t *keys = nullptr, *skeys = nullptr, *svals = nullptr, *first = nullptr, *filled = nullptr;
@@ -184,7 +212,7 @@ hipError_t positions_fill(const IndexDev& ix, const uint8_t* d_reads, uint64_t l
     for (uint64_t w0 = 0; e == hipSuccess && w0 < nwin_all; w0 += pw) {
         const uint64_t nwin = std::min(pw, nwin_all - w0);
         const uint64_t rel_start = start > w0 ? start - w0 : 0;               // windows before `start` get no bucket (hash.cpp:973-986)
-        hipLaunchKernelGGL(k_a2_probe, dim3(grid_of(nwin)), dim3(kB), 0, s, ix, d_reads + w0, nwin, rel_start, keys);
+        launch_a2_probe(ix, d_reads + w0, nwin, rel_start, keys, s);
         e = hipGetLastError();
         size_t tb = tmp_bytes;                                                  // sized for pw >= nwin elements
         if (e == hipSuccess) e = rocprim::radix_sort_pairs(tmp, tb, keys, skeys, iota, svals, (size_t)nwin, 0u, end_bit, s);
@@ -330,7 +358,16 @@ hipError_t distinct_from_plain(const uint8_t* d_plain, uint64_t plen, int k, int
         e = codes.alloc(8 * nwin);
         if (e == hipSuccess) e = launch_window_codes(d_plain + w0, nwin + k - 1, k, canon_mode, (uint64_t*)codes.p, s);
         uint64_t* pk = nullptr; uint32_t* pc = nullptr; uint64_t pm = 0;
-        if (e == hipSuccess) e = distinct_from_codes((uint64_t*)codes.p, nwin, k, 1, &pk, &pc, &pm, s);
+        bool sorted_path = !k1_msd_eligible(nwin, k);
+        if (e == hipSuccess && !sorted_path) {                                // MSD partition + per-bucket LDS hash / sort (aix_k1.hip)
+            bool fell_back = false;
+            e = distinct_from_codes_msd((uint64_t*)codes.p, nwin, k, &pk, &pc, &pm, &fell_back, s);
+            if (e == hipSuccess && fell_back) {                               // a bucket too rich for LDS: the codes were used as staging, make them again
+                sorted_path = true;
+                e = launch_window_codes(d_plain + w0, nwin + k - 1, k, canon_mode, (uint64_t*)codes.p, s);
+            }
+        }
+        if (e == hipSuccess && sorted_path) e = distinct_from_codes((uint64_t*)codes.p, nwin, k, 1, &pk, &pc, &pm, s);
         DevArr hold_k(s), hold_c(s); hold_k.p = pk; hold_c.p = pc;
         if (e != hipSuccess || pm == 0) continue;
         // concatenate {acc, piece} as (key, u64 count), sort by key, sum equal keys

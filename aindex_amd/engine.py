@@ -359,7 +359,7 @@ class Index:
         head_len, start = 1 << 16, C.c_uint64()
         while True:
             head = reads_t[:head_len].cpu().numpy()
-            check(lib().aix_positions_start(_np_ptr(head), head.shape[0], C.byref(start)), "aix_positions_start")
+            check(lib().aix_positions_start_k(_np_ptr(head), head.shape[0], self.k, C.byref(start)), "aix_positions_start_k")
             if head.shape[0] == reads_t.numel() or start.value + 64 < head.shape[0]:
                 break
             head_len *= 16

@@ -5,6 +5,7 @@
     python -m aindex_amd.tools compute_mphf_seq <keys.txt> [out.pf]
     python -m aindex_amd.tools compute_index <dat> <pf> <prefix> <threads> <mock>
     python -m aindex_amd.tools compute_aindex <reads> <pf> <prefix> <threads> 23 <tf> <kmers.bin> <kmers.txt> [index.bin indices.bin]
+    python -m aindex_amd.tools compute_aindex13 <reads> <pf> <tf.bin> <prefix> <threads> [pos_bin] [index.bin] [indices.bin]
     python -m aindex_amd.tools compute_reads <file1> <file2|-> <fastq|fasta|se|reads> <prefix>     (host-side, no GPU)
 
 `threads` arguments are accepted and ignored (the work runs on the GPU). Exit status 0 on success.
@@ -213,7 +214,25 @@ def compute_aindex(argv) -> int:
     return 0
 
 
-COMMANDS = {"count_kmers13": count_kmers13, "kmer_counter": kmer_counter, "compute_mphf_seq": compute_mphf_seq, "compute_index": compute_index,
+def compute_aindex13(argv) -> int:
+    """compute_aindex13.cpp:323-409: <reads> <pf> <tf.bin> <prefix> <threads> [pos_bin] [index_bin] [indices_bin] (the optional
+    names are argv[7] / argv[8] there, :343-344). N3: positions index of the 13-mers, forward strand, tf = the u64[4^13]
+    table count_kmers13 wrote (the reference tool misreads that file as u32, compute_aindex13.cpp:46-47)."""
+    if len(argv) < 5:
+        print("Expected arguments: compute_aindex13 <reads_file> <hash_file> <tf_file> <output_prefix> <num_threads> [pos_bin] [index_bin] [indices_bin]",
+              file=sys.stderr)
+        return 1
+    reads_file, pf, tf_file, prefix = argv[:4]
+    index_bin = argv[6] if len(argv) > 6 else prefix + ".index.bin"
+    indices_bin = argv[7] if len(argv) > 7 else prefix + ".indices.bin"
+    with Index.open_13(pf, tf_file) as ix:
+        indices, pos = ix.positions_fill(open(reads_file, "rb").read())
+    pos.tofile(index_bin)
+    indices.tofile(indices_bin)
+    return 0
+
+
+COMMANDS = {"compute_aindex13": compute_aindex13, "count_kmers13": count_kmers13, "kmer_counter": kmer_counter, "compute_mphf_seq": compute_mphf_seq, "compute_index": compute_index,
             "compute_reads": compute_reads, "compute_aindex": compute_aindex}
 
 

@@ -152,8 +152,15 @@ class AindexWrapper:
             self.load_reads(reads_file)
 
     def load_13mer_aindex(self, index_file: str, indices_file: str):
-        """:439-471 maps only the indices; 13-mer positions are never set, so queries return []."""
+        """:439-471. The reference maps only `.indices.bin` here and never sets `positions_13mer`, so its 13-mer position
+        queries always answer []; the mirror maps BOTH files (the `.index.bin` our compute_aindex13 writes, N3) so that
+        get_positions_13mer (:1070-1100) can answer what it is written to answer. A missing index file keeps the reference's
+        behaviour (indices only, queries return [])."""
         self._need(indices_file)
+        self._indices13 = np.memmap(indices_file, dtype=np.uint64, mode="r")
+        self._positions13 = None
+        if index_file and os.path.isfile(index_file) and os.path.getsize(index_file):
+            self._positions13 = np.memmap(index_file, dtype=np.uint64, mode="r")
         self.aindex_loaded = True
 
     def load_aindex_from_prefix_13mer(self, prefix: str, reads_file: str = ""):
@@ -163,7 +170,10 @@ class AindexWrapper:
         """compute_aindex replacement (A1/A2 on the GPU): returns (indices, positions) and, with a prefix,
         writes `<prefix>.indices.bin` / `<prefix>.index.bin` exactly like the reference (hash.hpp:470-486)."""
         reads = open(reads_file, "rb").read()
-        indices, pos = self._need23().positions_fill(reads)
+        if self._is_13mer_mode and self._ix13 is not None:              # N3: compute_aindex13 (forward strand, strict ACGT, u64 tf)
+            indices, pos = self._ix13.positions_fill(reads)
+        else:
+            indices, pos = self._need23().positions_fill(reads)
         if prefix:
             pos.tofile(prefix + ".index.bin")
             indices.tofile(prefix + ".indices.bin")
@@ -437,7 +447,24 @@ class AindexWrapper:
         return []
 
     def get_positions_13mer(self, kmer: str) -> List[int]:
-        return []                                    # positions_13mer is never mapped in the reference (:439-471)
+        """:1070-1100 — 13-mer mode, exactly 13 upper-case A/C/G/T, bucket = mphf(kmer), the non-zero entries of
+        positions[indices[h] : indices[h + 1]] minus one (0-based). [] when no positions file is mapped (the reference's
+        permanent state, see load_13mer_aindex)."""
+        if not self._is_13mer_mode or self._ix13 is None or getattr(self, "_positions13", None) is None:
+            return []
+        b = _enc(kmer)
+        if len(b) != 13 or any(c not in b"ACGT" for c in b):
+            return []
+        h = self._mphf13_slot(b)
+        if h >= TOTAL_13MERS:
+            return []
+        lo, hi = int(self._indices13[h]), min(int(self._indices13[h + 1]), int(self._positions13.shape[0]))
+        seg = np.asarray(self._positions13[lo:hi])
+        return (seg[seg != 0] - np.uint64(1)).tolist()
+
+    def _mphf13_slot(self, kmer13: bytes) -> int:
+        """hasher_13mer.lookup(kmer) (:1087) through the library (aix_hash_batch_ascii on the 13-mer handle)."""
+        return int(self._ix13.hash_ascii(kmer13)[0])
 
     def get_positions_23mer(self, kmer: str) -> List[int]:
         """:800-822 via PHASH_MAP::get_pfid (hash.hpp:150-170): the lexicographically smaller of the k-mer and the

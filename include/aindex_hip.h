@@ -162,7 +162,8 @@ int aix_tf_batch_ragged_dev(aix_index_t* h, const char* d_bytes, const uint64_t*
 
 /* instrumentation for the roofline accounting: d_out[i] = MPHF + key records that tf query i reads (23-mer handles) */
 int aix_lines_batch_ascii_dev(aix_index_t* h, const char* d_kmers, uint64_t N, uint32_t* d_out, void* stream);
-/* get_hash_values / get_hash_value (python_wrapper.cpp:629-642): raw mphf::lookup of the bytes */
+/* get_hash_values / get_hash_value (python_wrapper.cpp:629-642): raw mphf::lookup of the bytes. On a 13-mer handle: the
+ * value of hasher_13mer.lookup (:1087, used by get_positions_13mer) — the reference crashes there (hash_map is null). */
 int aix_hash_batch_ascii(aix_index_t* h, const char* kmers, uint64_t N, uint64_t* out);
 int aix_hash_batch_ascii_dev(aix_index_t* h, const char* d_kmers, uint64_t N, uint64_t* d_out, void* stream);
 /* get_kid_by_kmer (:700-716; 0 when absent) and get_strand (:726-742; 0 absent,1 fwd,2 rc) */
@@ -221,7 +222,14 @@ int aix_window_codes_dev(const char* d_plain, uint64_t len, int k, int canon_mod
  * strand, positions[indices[h] + slot] = offset + 1 for the first tf[h] occurrences in ascending offset order —
  * the result of the reference run with ONE thread (lu_compressed_worker, src/hash.cpp:960-1060; its multi-thread
  * slot order is schedule dependent). positions_out may be NULL to query *total_out = indices[n] first.
- * Any length: buffers of more than 2^30 windows are filled piece by piece, per-bucket fill counters carried over. */
+ * Any length: buffers of more than 2^30 windows are filled piece by piece, per-bucket fill counters carried over.
+ *
+ * 13-mer handles (N3: replaces `compute_aindex13 <reads> <pf> <tf> <prefix> <threads>`, src/compute_aindex13.cpp:36-71,
+ * 109-226,298-321): n = 4^13 buckets in MPHF order, tf = the handle's u64[4^13] table (what count_kmers13 writes), a window
+ * counts iff its 13 bytes are upper-case A/C/G/T, forward strand only, same slot rule and start adjustment. The reference tool
+ * itself reads the u64 tf file as u32[4^13] (compute_aindex13.cpp:46-47) and therefore indexes a scrambled table; handing this
+ * entry point that misread view (widened to u64) reproduces the reference's files bit for bit, which is how the path is pinned
+ * (tests/golden/aindex13). All positions entry points below accept 13-mer handles in the same way. */
 int aix_positions_fill(aix_index_t* h, const char* reads, uint64_t len, uint64_t* indices_out, uint64_t* positions_out,
                        uint64_t positions_cap, uint64_t* total_out);
 /* device-resident twin (reads, indices and positions in HBM; returns after the fill has completed on `stream`):
@@ -241,6 +249,7 @@ int aix_positions_bucket_counts(aix_index_t* h, const char* reads, uint64_t len,
 /* the start adjustment itself (host only): first window offset the reference's single worker looks at. A shard whose
  * adjusted start is >= its window count has no clean window, and the adjustment carries on into the next shard. */
 int aix_positions_start(const char* reads, uint64_t len, uint64_t* start_out);
+int aix_positions_start_k(const char* reads, uint64_t len, int k /* 23 or 13 */, uint64_t* start_out);
 int aix_positions_fill_shard(aix_index_t* h, const char* reads, uint64_t len, int first_shard, uint64_t base_offset,
                              const uint32_t* filled_init, uint64_t* positions_out, uint64_t positions_cap);
 /* K1 complete: replaces `kmer_counter <in.fa> <k> <out> [-t N] [-m min]` (src/count_kmers.cpp:235-382): the set of

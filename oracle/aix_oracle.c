@@ -620,4 +620,42 @@ void aixo_positions_fill(const aixo_index23* ix, const char* c, uint64_t len, co
     free(pp);
 }
 
+/* =====================================================================================
+ * N3: 13-mer positions index — src/compute_aindex13.cpp:36-71 (indices), :109-226 (worker, one thread).
+ * tf is the u64[4^13] table count_kmers13 writes. The reference reads that file as u32[4^13]
+ * (compute_aindex13.cpp:46-47); its behaviour is reproduced by handing THIS function the misread
+ * view widened to u64 (tests/golden/make_golden.py does so), which is how the restatement is pinned.
+ * ===================================================================================== */
+void aixo_indices_prefix64(const uint64_t* tf, uint64_t n, uint64_t* indices) {           /* :57-63 */
+    indices[0] = 0;
+    for (uint64_t i = 1; i < n + 1; ++i) indices[i] = indices[i - 1] + tf[i - 1];
+}
+void aixo_positions_fill13(const aixo_mphf* f, const char* c, uint64_t len, const uint64_t* indices, uint64_t* positions) {
+    const uint64_t k = 13, N13 = 67108864ull;
+    if (len < k) return;
+    uint64_t start = 0, end = len;
+    const uint64_t total = indices[N13];
+    uint64_t* pp = (uint64_t*)calloc(N13, 8);                          /* ppositions, :66-71 */
+    while (start < end - k + 1) {                                     /* :135-148 */
+        int found = 0;
+        for (uint64_t i = start; i < start + k; ++i)
+            if (c[i] == '\n' || c[i] == '~' || c[i] == '?') { start = i + 1; found = 1; break; }
+        if (!found) break;
+    }
+    for (uint64_t i = start; i < end - k + 1; ++i) {                   /* :163 */
+        int skip = 0;
+        for (uint64_t j = 0; j < k; ++j) {                            /* :183-190: anything but upper-case ACGT skips the window */
+            const char ch = c[i + j];
+            if (ch != 'A' && ch != 'T' && ch != 'G' && ch != 'C') { skip = 1; break; }
+        }
+        if (skip) continue;
+        const uint64_t h = aixo_mphf_lookup(f, (const uint8_t*)(c + i), 13);   /* :203, forward strand only (lookup never throws) */
+        if (h >= N13) continue;
+        const uint64_t slot = pp[h]++;                                /* :205 */
+        const uint64_t idx = indices[h] + slot;
+        if (idx < total && slot < indices[h + 1] - indices[h]) positions[idx] = i + 1;   /* :208-211, 1-based */
+    }
+    free(pp);
+}
+
 void aixo_free(void* p) { free(p); }

@@ -116,6 +116,10 @@ int aixo_index_scatter(const aixo_mphf* f, const char* keys, const uint32_t* tfs
 void aixo_indices_prefix(const uint32_t* tf, uint64_t n, uint64_t* indices /* n+1 */);
 void aixo_positions_fill(const aixo_index23* ix, const char* reads, uint64_t len,
                          const uint64_t* indices, uint64_t* positions /* zeroed, indices[n] */);
+/* ---- N3: 13-mer positions index, src/compute_aindex13.cpp:36-71,109-226 (1 thread), tf as u64[4^13] ---- */
+void aixo_indices_prefix64(const uint64_t* tf, uint64_t n, uint64_t* indices /* n + 1 */);
+void aixo_positions_fill13(const aixo_mphf* f, const char* reads, uint64_t len, const uint64_t* indices /* 4^13 + 1 */,
+                           uint64_t* positions /* zeroed, indices[4^13] */);
 
 void aixo_free(void* p);
 

@@ -391,6 +391,36 @@ def make_count13(pf):
     print("q13 queries", len(q), "nonzero", sum(1 for x in exp["tf"] if x))
 
 
+def make_aindex13(pf):
+    """N3: the reference's compute_aindex13 (1 thread) on count13/synth.txt with the tf file its own count_kmers13 wrote.
+    The tool reads that u64 file as u32 (compute_aindex13.cpp:46-47), so its output is the positions index of the MISREAD
+    table tf32[i] = i-th 32-bit word of the file; the tests hand that view (widened to u64) to our implementation and to the
+    oracle restatement and expect the reference's files. Fixture: the positions array and a digest of the 537 MB indices file."""
+    import hashlib
+    d = os.path.join(GOLD, "aindex13")
+    os.makedirs(d, exist_ok=True)
+    w = os.path.join(TMP, "aindex13")
+    os.makedirs(w, exist_ok=True)
+    reads = os.path.join(GOLD, "count13", "synth.txt")
+    tfb = os.path.join(w, "synth.tf.bin")
+    run([os.path.join(REF, "count_kmers13"), reads, pf, tfb, "2"])
+    prefix = os.path.join(w, "a13")
+    run([os.path.join(REF, "compute_aindex13"), reads, pf, tfb, prefix, "1"])
+    pos = np.fromfile(prefix + ".index.bin", dtype=np.uint64)
+    h = hashlib.sha256()
+    with open(prefix + ".indices.bin", "rb") as f:
+        for blk in iter(lambda: f.read(1 << 24), b""):
+            h.update(blk)
+    ind = np.fromfile(prefix + ".indices.bin", dtype=np.uint64)
+    view = np.fromfile(tfb, dtype=np.uint32)[: 4 ** 13]
+    assert int(ind[-1]) == pos.shape[0] == int(view.astype(np.uint64).sum())
+    np.savez_compressed(os.path.join(d, "synth.npz"), positions=pos, indices_sha256=np.frombuffer(h.digest(), dtype=np.uint8),
+                        total=np.array([pos.shape[0]], dtype=np.uint64), indices_sample=ind[:: 1 << 16])
+    print("aindex13: total slots", pos.shape[0], "filled", int((pos != 0).sum()))
+    for f in (tfb, prefix + ".index.bin", prefix + ".indices.bin"):
+        os.remove(f)
+
+
 def make_compute_reads():
     """N4: compute_reads outputs (.reads/.ridx/.header) for every input mode, on the reference's own tiny inputs."""
     d = os.path.join(GOLD, "compute_reads")
@@ -439,3 +469,5 @@ if __name__ == "__main__":
     if not only or "13" in only:
         pf = make_pf13(a.skip_13mer_pf)
         make_count13(pf)
+    if not only or "aindex13" in only:
+        make_aindex13(os.path.join(ROOT, "data", "all_13mers.pf"))       # the all-13-mers .pf (sha256 pinned in pf13.json)

@@ -217,6 +217,17 @@ def count13(mphf: OracleMphf, buf: bytes, fmt: int = -1, threads: int = 1) -> np
     return counts
 
 
+def positions13(mphf: OracleMphf, tf64: np.ndarray, reads: bytes):
+    """N3 restatement (compute_aindex13.cpp, one thread) with tf as u64[4^13]: (indices u64[4^13 + 1], positions u64[sum tf])."""
+    tf64 = np.ascontiguousarray(tf64, dtype=np.uint64)
+    assert tf64.shape[0] == 4 ** 13
+    indices = np.zeros(4 ** 13 + 1, dtype=np.uint64)
+    lib().aixo_indices_prefix64(_p(tf64, u64p), C.c_uint64(4 ** 13), _p(indices, u64p))
+    pos = np.zeros(int(indices[-1]), dtype=np.uint64)
+    lib().aixo_positions_fill13(C.byref(mphf.s), reads, C.c_uint64(len(reads)), _p(indices, u64p), _p(pos, u64p))
+    return indices, pos
+
+
 def count_distinct(fasta: bytes, k: int, canon_mode: int, min_count: int = 1):
     kp, cp = u64p(), u64p()
     m = lib().aixo_count_distinct(fasta, len(fasta), k, canon_mode, min_count, C.byref(kp), C.byref(cp))

@@ -14,7 +14,7 @@ from aindex_amd import _lib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "bin")
-SHIMS = ("count_kmers13", "kmer_counter", "compute_mphf_seq", "compute_index", "compute_aindex", "compute_reads")
+SHIMS = ("count_kmers13", "kmer_counter", "compute_mphf_seq", "compute_index", "compute_aindex", "compute_aindex13", "compute_reads")
 
 
 def _run(name, *args, cwd=None):
@@ -25,7 +25,7 @@ def _run(name, *args, cwd=None):
 def test_shim_is_an_executable_with_the_reference_name_and_usage_status(name):
     """cli.py:243-262 looks for <bin>/<name> and runs it; without arguments every reference tool prints its usage and exits
     non-zero (count_kmers13.cpp:546-551, count_kmers.cpp:394-399, compute_mphf_generic.hpp:21-26, compute_index.cpp:36-41,
-    compute_aindex.cpp:30-35, compute_reads.cpp:24-29)."""
+    compute_aindex.cpp:30-35, compute_aindex13.cpp:324-338, compute_reads.cpp:24-29)."""
     path = os.path.join(BIN, name)
     assert os.path.isfile(path) and os.access(path, os.X_OK)
     r = _run(name)

@@ -1192,6 +1192,102 @@ def test_early_exit_walk_on_off(canon_case, ix23, q23):
     assert float(((li >> 12) & 15).mean()) == 1.0 and float((li >> 16).mean()) < 0.05   # filter on: one cached word, absent keys rarely reach the table
 
 
+def test_positions13_reference_pin_oracle_pieces_and_mirror(gold, tmp_path, monkeypatch):
+    """N3 (compute_aindex13): (a) pinned to the reference — the tool indexes the tf file misread as u32 (compute_aindex13.cpp:46-47);
+    a handle holding that view (widened to u64) must reproduce the reference's 1-thread .index.bin / .indices.bin
+    (tests/golden/aindex13); (b) with the real u64 table: equal to the oracle restatement, in one piece, cut into pieces, and through
+    the device-resident twin; (c) the compute_aindex13 shim writes those files and the AindexWrapper mirror answers
+    get_positions_13mer from them (the reference never maps its positions file, python_wrapper.cpp:439-471)."""
+    import hashlib
+    import subprocess
+    import torch
+    from pf13 import pf13_path
+    from test_oracle_golden13 import _misread_tf_view
+    g = np.load(os.path.join(gold, "aindex13", "synth.npz"))
+    reads = open(os.path.join(gold, "count13", "synth.txt"), "rb").read()
+    m = O.OracleMphf(pf13_path())
+    with Index.open_13(pf13_path(), None) as ix:
+        ix.set_tf_13(_misread_tf_view(gold))                                        # (a)
+        indices, pos = ix.positions_fill(reads)
+        assert np.array_equal(pos, g["positions"]) and int((pos != 0).sum()) > 0
+        assert hashlib.sha256(indices.tobytes()).digest() == bytes(g["indices_sha256"])
+        tf = ix.count13(reads, _lib.FMT_PLAIN)                                      # (b) the table count_kmers13 writes for these reads
+        ix.set_tf_13(tf)
+        noisy = reads[:40_000] + b"acgtacgtacgtacgtacgt\nACGTNACGTACGTACGTRACGT~ACGTACGTACGTACGTAC?GGGGGGGGGGGGGGGG\n" + reads[40_000:90_000]
+        for buf in (reads, noisy, b"?AC\n" + reads[:5000], b"ACGTACGTACGTA", b"ACGT", b""):
+            oind, opos = O.positions13(m, tf, buf)
+            ind, pos = ix.positions_fill(buf)
+            assert np.array_equal(ind, oind) and np.array_equal(pos, opos), len(buf)
+            for piece in ("1000", "77777"):
+                monkeypatch.setenv("AIX_POSITIONS_PIECE", piece)
+                ind2, pos2 = ix.positions_fill(buf)
+                monkeypatch.delenv("AIX_POSITIONS_PIECE")
+                assert np.array_equal(pos2, opos), (len(buf), piece)
+            if buf:
+                t = torch.frombuffer(bytearray(buf), dtype=torch.uint8).cuda()
+                indt, post = ix.positions_fill_t(t)
+                assert np.array_equal(indt.cpu().numpy().view(np.uint64), oind) and np.array_equal(post.cpu().numpy().view(np.uint64), opos)
+        assert int((opos != 0).sum()) == 0                                          # (the empty buffer came last)
+        oind, opos = O.positions13(m, tf, reads)
+        assert int((opos != 0).sum()) == int(tf.sum())                              # every counted window got its slot
+        # hasher_13mer.lookup through the ABI == the oracle's MPHF
+        ks = [reads[i:i + 13] for i in (0, 7, 150, 2000)] + [b"ACGTNACGTACGT"]
+        assert ix.hash_ascii(b"".join(ks)).tolist() == [m.lookup(k) for k in ks]
+    # (c) the tool front end and the Python mirror
+    prefix = str(tmp_path / "a13")
+    tf.tofile(prefix + ".tf.bin")
+    rp = str(tmp_path / "synth.reads")
+    open(rp, "wb").write(reads)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([os.path.join(root, "bin", "compute_aindex13"), rp, pf13_path(), prefix + ".tf.bin", prefix, "4"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert np.array_equal(np.fromfile(prefix + ".index.bin", dtype=np.uint64), opos)
+    assert np.array_equal(np.fromfile(prefix + ".indices.bin", dtype=np.uint64), oind)
+    os.symlink(pf13_path(), prefix + ".pf")
+    from aindex_amd.wrapper import AindexWrapper
+    w = AindexWrapper()
+    w.load_from_prefix_13mer(prefix)
+    assert w.get_positions_13mer(reads[:13].decode()) == []                        # nothing mapped yet: the reference's permanent answer
+    w.load_aindex_from_prefix_13mer(prefix)
+    for k in (reads[:13], reads[150:163], b"ACGTACGTACGTA", b"AAAAAAAAAAAAA"):
+        h = m.lookup(k)
+        seg = opos[int(oind[h]):int(oind[h + 1])]
+        assert w.get_positions_13mer(k.decode()) == (seg[seg != 0] - np.uint64(1)).tolist()
+        assert w.get_positions(k.decode()) == w.get_positions_13mer(k.decode())
+    assert w.get_positions_13mer("ACGTNACGTACGT") == [] and w.get_positions_13mer("acgtacgtacgta") == [] and w.get_positions_13mer("ACGT") == []
+    ind_b, pos_b = w.build_aindex(rp)
+    assert np.array_equal(pos_b, opos)
+    w.close()
+
+
+def test_kmer_counter_msd_path_equals_radix_path_and_oracle(monkeypatch):
+    """K1 without a full-width sort (aix_k1.hip: two-level MSD partition + per-bucket LDS hash / sort) against the radix-sort
+    path (AIX_K1_ROCPRIM=1) and the oracle: uniform reads, a heavy hitter (poly-A: one hash slot, many adds), k = 13 and k = 23,
+    every canonical mode, min_count, and an input whose codes share their top 20 bits so that buckets overflow and the call falls
+    back (same answer either way)."""
+    from aindex_amd import counting
+    rng = np.random.default_rng(5)
+    asc = synth.genome_ascii(77, 400_000)
+    reads = synth.reads_plain(43, asc, 6000, 150, rc_fraction_half=True, n_rate_ppm=2000).tobytes()
+    polya = (b"A" * 150 + b"\n") * 3000 + (b"ACGT" * 37 + b"AC\n") * 500 + reads[:200_000]
+    prefix = b"AAAAAAAAAA"
+    narrow = b"".join(prefix + bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 13)) + b"\n" for _ in range(60_000))
+    cases = [(reads, 23, 2, 1), (reads, 23, 1, 2), (reads, 13, 2, 1), (polya, 23, 1, 1), (polya, 23, 2, 3), (narrow, 23, 0, 1), (narrow, 13, 0, 1), (b"", 23, 1, 1),
+             (b"ACGTACGTACGTACGTACGTACG\n", 23, 1, 1)]
+    for buf, k, mode, minc in cases:
+        monkeypatch.delenv("AIX_K1_ROCPRIM", raising=False)
+        keys, counts = counting.count_distinct(buf, k, mode, minc, fmt=_lib.FMT_PLAIN)
+        monkeypatch.setenv("AIX_K1_ROCPRIM", "1")
+        rkeys, rcounts = counting.count_distinct(buf, k, mode, minc, fmt=_lib.FMT_PLAIN)
+        assert np.array_equal(keys, rkeys) and np.array_equal(counts, rcounts), (len(buf), k, mode, minc)
+        okeys, ocnt = O.count_distinct(b">r\n" + buf.replace(b"\n", b"\n>r\n") if buf else buf, k, mode, minc)
+        assert np.array_equal(keys, okeys) and np.array_equal(counts, ocnt.astype(np.uint64)), (len(buf), k, mode, minc)
+    monkeypatch.delenv("AIX_K1_ROCPRIM", raising=False)
+    monkeypatch.setenv("AIX_K1_TEST_REGION", "40")                 # an undersized chunk region must fail loudly, not drop k-mers
+    with pytest.raises(_lib.AixError):
+        counting.count_distinct(reads, 23, 2, 1, fmt=_lib.FMT_PLAIN)
+
+
 def test_count23_histogram_backend_equals_atomics_and_oracle(canon_case, small23_prefix, monkeypatch):
     """k_count23_fixed's two back ends: one memory-side atomic per found window, or the slot stream + chunked-partition LDS
     histogram (no global atomics; the default for long buffers). Forced onto small inputs here, in one piece and cut into
