@@ -38,8 +38,9 @@ static constexpr int K1_FILLBITS = 8;                 // cursor = (chunk << 8) |
 static constexpr int K1_DUMMY = 64;
 static constexpr unsigned K1_MAXGRID = 512;
 static constexpr int K1_FB = 256;                     // threads of the per-bucket workgroup
-static constexpr int K1_CAP = 4096;                   // hash slots per bucket
-static constexpr int K1_DMAX = 2048;                  // distinct remainders a bucket may hold
+static constexpr int K1_CAP = 2048;                   // hash slots per bucket
+static constexpr int K1_DMAX = 1536;                  // distinct remainders a bucket may hold (load <= 0.75)
+static constexpr int K1_PRE = 4;                      // entries per lane fetched ahead for the NEXT bucket (256 x 4 = 1024 entries)
 static constexpr uint64_t K1_INVALID = ~0ull;
 
 // ---------------------------------------------------------------------------------------------
@@ -294,18 +295,36 @@ __global__ void __launch_bounds__(K1_FB) k_k1_final(const uint32_t* __restrict__
     __shared__ uint32_t dc[K1_DMAX];
     __shared__ uint32_t ndist, m_out;
     const uint32_t t = threadIdx.x;
+    // A bucket is ~10^3 entries: its global loads (two bases, then the entries) are a dependent chain of HBM latencies that
+    // would dominate the few microseconds of LDS work. The base pair and the first 1024 entries of the NEXT bucket are therefore
+    // fetched into registers while this one is processed.
+    uint32_t nlo = 0, nn = 0, pre[K1_PRE];
+    auto prefetch = [&](uint32_t b) {
+        nn = 0;
+        if (b < nbuckets) {
+            nlo = bucket_base[b];
+            nn = bucket_base[b + 1] - nlo;
+#pragma unroll
+            for (int q = 0; q < K1_PRE; ++q) { const uint32_t i = t + q * K1_FB; pre[q] = i < nn ? in32[nlo + i] : 0u; }
+        }
+    };
+    prefetch(blockIdx.x);
     for (uint32_t b = blockIdx.x; b < nbuckets; b += gridDim.x) {
-        const uint32_t lo = bucket_base[b], n_e = bucket_base[b + 1] - lo;
+        const uint32_t lo = nlo, n_e = nn;
+        uint32_t cur[K1_PRE];
+#pragma unroll
+        for (int q = 0; q < K1_PRE; ++q) cur[q] = pre[q];
+        prefetch(b + gridDim.x);
         if (n_e == 0) { if (t == 0) distinct_m[b] = 0; continue; }
         // table size: a power of two >= 2 x (the most distinct remainders this bucket can be allowed to hold)
         uint32_t cap = 64;
         const uint32_t want = 2u * min(n_e, (uint32_t)K1_DMAX);
-        while (cap < want) cap <<= 1;
+        while (cap < want && cap < (uint32_t)K1_CAP) cap <<= 1;
         for (uint32_t i = t; i < cap; i += K1_FB) { hk[i] = 0; hc[i] = 0; }
         if (t == 0) { ndist = 0; m_out = 0; }
         __syncthreads();
-        for (uint32_t i = t; i < n_e; i += K1_FB) {
-            const uint32_t key = in32[lo + i] + 1u;              // remainders are < 2^31 (s2 <= 31): + 1 cannot wrap to the empty marker
+        auto insert = [&](uint32_t v) {
+            const uint32_t key = v + 1u;                         // remainders are < 2^31 (s2 <= 31): + 1 cannot wrap to the empty marker
             uint32_t h = (key * 0x9E3779B1u) >> 7;
             for (uint32_t probes = 0; probes < cap; ++probes) {
                 h &= cap - 1;
@@ -314,7 +333,10 @@ __global__ void __launch_bounds__(K1_FB) k_k1_final(const uint32_t* __restrict__
                 if (old == 0u || old == key) { atomicAdd(&hc[h], 1u); break; }
                 ++h;
             }
-        }
+        };
+#pragma unroll
+        for (int q = 0; q < K1_PRE; ++q) if (t + q * K1_FB < n_e) insert(cur[q]);
+        for (uint32_t i = t + K1_PRE * K1_FB; i < n_e; i += K1_FB) insert(in32[lo + i]);      // the tail of an oversized bucket
         __syncthreads();
         const uint32_t nd = ndist;
         if (nd > (uint32_t)K1_DMAX) {                            // too many distinct remainders for the LDS arrays (or a full table dropped some)
@@ -392,7 +414,7 @@ hipError_t distinct_from_codes_msd(uint64_t* d_codes, uint64_t nwin, int k, uint
     const uint32_t B = 2u * (uint32_t)k, s1 = B - K1_PBITS;
     // D2: ~768 codes per bucket on average; the remainder must fit 32 bits
     uint32_t D2 = 3;
-    while (D2 < 11 && (nwin >> (K1_PBITS + D2)) > 768) ++D2;
+    while (D2 < 11 && (nwin >> (K1_PBITS + D2)) > 640) ++D2;
     while (s1 - D2 > 31) ++D2;                                  // remainder + 1 must not wrap (0 marks an empty hash slot)
     if (D2 > s1) D2 = s1;
     const uint32_t s2 = s1 - D2, nb2 = 1u << D2;
@@ -412,8 +434,8 @@ hipError_t distinct_from_codes_msd(uint64_t* d_codes, uint64_t nwin, int k, uint
     (void)rocprim::exclusive_scan(nullptr, scan_tmp, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)nbuckets + 1, rocprim::plus<uint32_t>(), s);
     const uint64_t o_flags = 0, o_dirp = 256, o_dirc = o_dirp + up256(2ull * cap), o_spart = o_dirc + up256(2ull * cap), o_sdesc = o_spart + up256(2ull * cap),
                    o_stmp = o_sdesc + up256(8ull * cap), o_bcnt = o_stmp + up256(std::max(sort_tmp, scan_tmp)), o_bbase = o_bcnt + up256(4ull * (nbuckets + 1)),
-                   o_dm = o_bbase + up256(4ull * (nbuckets + 1)), o_dmo = o_dm + up256(4ull * (nbuckets + 1)), o_out32 = o_dmo + up256(4ull * (nbuckets + 1)),
-                   o_parts = o_out32 + up256(4ull * nwin), total = o_parts + 8ull * cap * K1_CH;
+                   o_dm = o_bbase + up256(4ull * (nbuckets + 1)), o_dmo = o_dm + up256(4ull * (nbuckets + 1)), o_parts = o_dmo + up256(4ull * (nbuckets + 1)),
+                   total = o_parts + 8ull * cap * K1_CH;
     uint8_t* w = nullptr;
     hipError_t e = pool_alloc((void**)&w, total);
     if (e != hipSuccess) return e;
@@ -428,8 +450,12 @@ hipError_t distinct_from_codes_msd(uint64_t* d_codes, uint64_t nwin, int k, uint
     uint32_t* bucket_base = (uint32_t*)(w + o_bbase);
     uint32_t* distinct_m = (uint32_t*)(w + o_dm);
     uint32_t* dm_off = (uint32_t*)(w + o_dmo);
-    uint32_t* out32 = (uint32_t*)(w + o_out32);
+    // the code array (8 B per window) is free once level 1 has read it: its first half takes the 32-bit remainders of level 2,
+    // its second half the per-bucket counts; the chunk array (>= 8 B per window) is free after level 2 and takes the per-bucket keys
+    uint32_t* out32 = (uint32_t*)d_codes;
+    uint32_t* cnt_st = (uint32_t*)d_codes + nwin;
     uint64_t* parts = (uint64_t*)(w + o_parts);
+    uint64_t* keys_st = parts;
     uint64_t* keys = nullptr;
     uint32_t* counts = nullptr;
     uint32_t flags[2] = {0, 0};
@@ -454,10 +480,7 @@ hipError_t distinct_from_codes_msd(uint64_t* d_codes, uint64_t nwin, int k, uint
         if (e != hipSuccess) break;
         hipLaunchKernelGGL(k_k1_scatter, dim3(K1_P), dim3(K1_TB), K1_TILE_LDS, s, (const uint64_t*)parts, (const uint16_t*)spart, (const uint64_t*)sdesc, cap, s2, nb2,
                            (const uint32_t*)bucket_base, out32);
-        // staging of the per-bucket results: keys over the (now consumed) code array, counts over the (now consumed) chunk array
-        uint64_t* keys_st = d_codes;
-        uint32_t* cnt_st = (uint32_t*)parts;
-        hipLaunchKernelGGL(k_k1_final, dim3(std::min<uint32_t>(nbuckets, 1u << 20)), dim3(K1_FB), 0, s, (const uint32_t*)out32, (const uint32_t*)bucket_base, nbuckets, s2,
+        hipLaunchKernelGGL(k_k1_final, dim3(std::min<uint32_t>(nbuckets, 256u * 5u)), dim3(K1_FB), 0, s, (const uint32_t*)out32, (const uint32_t*)bucket_base, nbuckets, s2,
                            keys_st, cnt_st, distinct_m, overflow);
         tb = scan_tmp;
         e = rocprim::exclusive_scan(tmp, tb, distinct_m, dm_off, 0u, (size_t)nbuckets + 1, rocprim::plus<uint32_t>(), s);
