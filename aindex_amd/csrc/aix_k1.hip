@@ -350,30 +350,43 @@ __global__ void __launch_bounds__(K1_FB) k_k1_final(const uint32_t* __restrict__
         }
         __syncthreads();
         const uint32_t m = m_out;
-        uint32_t mp = 1;
-        while (mp < m) mp <<= 1;
-        for (uint32_t i = m + t; i < mp; i += K1_FB) { dk[i] = 0xFFFFFFFFu; dc[i] = 0; }
-        __syncthreads();
-        for (uint32_t k = 2; k <= mp; k <<= 1) {                 // bitonic sort of (dk, dc) by dk, ascending
-            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                for (uint32_t i = t; i < mp; i += K1_FB) {
-                    const uint32_t x = i ^ j;
-                    if (x > i) {
-                        const uint32_t ka = dk[i], kb = dk[x];
-                        const bool up = (i & k) == 0;
-                        if ((ka > kb) == up) {
-                            dk[i] = kb; dk[x] = ka;
-                            const uint32_t ca = dc[i]; dc[i] = dc[x]; dc[x] = ca;
+        const uint64_t prefix = (uint64_t)b << s2;               // bucket id = the top 11 + D2 bits of the code
+        if (m <= 384u) {
+            // few distinct keys (the usual case: a bucket's ~10^3 entries are ~10^2 distinct k-mers at sequencing depth): every lane
+            // ranks its key by counting the smaller ones (broadcast reads, no conflicts) and stores it straight at its place — no
+            // further barrier, instead of the dozens a bitonic network needs
+            for (uint32_t i = t; i < m; i += K1_FB) {
+                const uint32_t key = dk[i];
+                uint32_t r = 0;
+                for (uint32_t j = 0; j < m; ++j) r += dk[j] < key ? 1u : 0u;
+                keys_out[lo + r] = prefix | key;
+                cnt_out[lo + r] = dc[i];
+            }
+        } else {
+            uint32_t mp = 1;
+            while (mp < m) mp <<= 1;
+            for (uint32_t i = m + t; i < mp; i += K1_FB) { dk[i] = 0xFFFFFFFFu; dc[i] = 0; }
+            __syncthreads();
+            for (uint32_t k = 2; k <= mp; k <<= 1) {             // bitonic sort of (dk, dc) by dk, ascending
+                for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                    for (uint32_t i = t; i < mp; i += K1_FB) {
+                        const uint32_t x = i ^ j;
+                        if (x > i) {
+                            const uint32_t ka = dk[i], kb = dk[x];
+                            const bool up = (i & k) == 0;
+                            if ((ka > kb) == up) {
+                                dk[i] = kb; dk[x] = ka;
+                                const uint32_t ca = dc[i]; dc[i] = dc[x]; dc[x] = ca;
+                            }
                         }
                     }
+                    __syncthreads();
                 }
-                __syncthreads();
             }
-        }
-        const uint64_t prefix = (uint64_t)b << s2;               // bucket id = the top 11 + D2 bits of the code
-        for (uint32_t i = t; i < m; i += K1_FB) {
-            keys_out[lo + i] = prefix | dk[i];
-            cnt_out[lo + i] = dc[i];
+            for (uint32_t i = t; i < m; i += K1_FB) {
+                keys_out[lo + i] = prefix | dk[i];
+                cnt_out[lo + i] = dc[i];
+            }
         }
         if (t == 0) distinct_m[b] = m;
         __syncthreads();
@@ -414,7 +427,7 @@ hipError_t distinct_from_codes_msd(uint64_t* d_codes, uint64_t nwin, int k, uint
     const uint32_t B = 2u * (uint32_t)k, s1 = B - K1_PBITS;
     // D2: ~768 codes per bucket on average; the remainder must fit 32 bits
     uint32_t D2 = 3;
-    while (D2 < 11 && (nwin >> (K1_PBITS + D2)) > 640) ++D2;
+    while (D2 < 11 && (nwin >> (K1_PBITS + D2)) > 900) ++D2;
     while (s1 - D2 > 31) ++D2;                                  // remainder + 1 must not wrap (0 marks an empty hash slot)
     if (D2 > s1) D2 = s1;
     const uint32_t s2 = s1 - D2, nb2 = 1u << D2;
