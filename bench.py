@@ -758,7 +758,8 @@ def main():
                                "collective_ranks": r["collective_ranks"], "one_device_rehearsal": r["one_device_rehearsal"]},
                     "allreduce_ms": r["allreduce_ms"], "allreduce_bytes": r["allreduce_bytes"], "tf_digest": r["tf_digest"],
                     "windows_counted_all_ranks": r["windows_counted_all_ranks"],
-                    "roofline": count23_roofline(ix, r["windows_this_rank"], r["reads_this_rank"], r["kernel_ms_this_rank"])})
+                    "roofline": {**count23_roofline(ix, r["windows_this_rank"], r["reads_this_rank"], r["kernel_ms_this_rank"]),
+                                 "calls_in_process": a.steps + a.warmup + 2}})
         tr = load_pmc_traffic("count23", reads_per_launch=r["reads_this_rank"])
         if tr:
             out["roofline"]["traffic"] = tr.get("bytes_per_launch")
@@ -783,7 +784,8 @@ def main():
                     "config": {"workload": "configs[3]-shaped: 23-mer histogram against a fixed MPHF, 150 bp reads, + all-reduce(sum) of tf[]; per-rank reads fixed (weak)",
                                "reads_per_step_per_gpu": a.reads, "index_keys": ix.n},
                     "tf_digest": digest,
-                    "roofline": count23_roofline(ix, windows, a.reads, kern_ms)})
+                    "roofline": {**count23_roofline(ix, windows, a.reads, kern_ms),
+                                 "calls_in_process": a.steps + a.warmup + 3 + (1 if cb23 else 0)}})      # for the per-call normalisation of the PMC passes
         tr = load_pmc_traffic("count23", reads_per_launch=a.reads)
         if tr:
             out["roofline"]["traffic"] = tr.get("bytes_per_launch")
@@ -867,7 +869,15 @@ def main():
         wall, kern_ms, _ = timed_steps(step, a.steps, a.warmup, dev)
         keys_t, counts_t = res["o"]
         windows = a.reads * (150 - 22)
-        achieved = (a.reads * 151 + windows * 8.0 * (1 + 2 * 6)) / (kern_ms * 1e-3) / 1e9      # codes written once, 6 radix passes read + write them
+        msd = os.environ.get("AIX_K1_ROCPRIM") is None
+        positions_n = a.reads * 151 - 22
+        distinct_n = int(keys_t.numel())
+        # requested by the kernels: the radix path writes the 8-byte codes once and moves them through 6 read+write passes; the MSD path
+        # (aix_k1.hip) writes the codes (8), level 1 reads and writes them (16), level 2 reads them twice and writes 4-byte remainders
+        # (20), the per-bucket stage reads those (4) and 12 bytes per distinct key go out twice
+        per_pos = 8.0 * (1 + 2 * 6) if not msd else (8.0 + 16.0 + 20.0 + 4.0)
+        requested = a.reads * 151 + positions_n * per_pos + (24.0 * distinct_n if msd else 12.0 * distinct_n)
+        achieved = requested / (kern_ms * 1e-3) / 1e9
         cb = None
         if rank == 0 and world == 1 and not a.no_cpu_baseline:
             ns = min(a.cpu_reads, a.reads)
@@ -879,7 +889,15 @@ def main():
                                "reads_per_step_per_gpu": a.reads, "windows": windows, "distinct_kmers": int(keys_t.numel())},
                     **({"cpu_baseline": cb.get("reference", cb["port_1t"]), "cpu_baseline_extra": cb} if cb else {}),
                     "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                                 "kernel": "k_window_codes + rocPRIM radix sort / run-length (aix_count_distinct_dev)", "kernel_ms": kern_ms}})
+                                 "kernel": ("k_window_codes + k_k1_split / k_k1_count / k_k1_scatter / k_k1_final / k_k1_gather (aix_count_distinct_dev)" if msd
+                                            else "k_window_codes + rocPRIM radix sort / run-length (aix_count_distinct_dev, AIX_K1_ROCPRIM=1)"),
+                                 "kernel_ms": kern_ms, "reads_per_launch": a.reads, "requested_bytes_per_launch": requested,
+                                 "calls_in_process": a.steps + a.warmup + (1 if cb else 0),
+                                 "note": "not HBM-bound: one returning LDS atomic per window and level (DESIGN.md §4)"}})
+        tr = load_pmc_traffic("distinct23", reads_per_launch=a.reads)
+        if tr:
+            out["roofline"]["traffic"] = tr.get("bytes_per_launch")
+            out["roofline"]["traffic_source"] = tr.get("source")
 
     elif a.workload == "positions23":
         from aindex_amd._lib import lib, check, vp
@@ -941,8 +959,13 @@ def main():
                                "reads": a.reads, "windows": windows, "positions_total": int(indices[-1]), "filled": int((pos != 0).sum()),
                                "host_buffer_call_ms": host_dt * 1e3, "host_buffer_reads_per_s": a.reads / host_dt},
                     "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                                 "kernel": "k_a2_probe + rocprim radix_sort_pairs + k_a2_first/k_a2_place (+ hipMalloc/hipFree of the sort buffers)",
-                                 "kernel_ms": kern_ms}})
+                                 "kernel": "k_a2_probe + rocprim radix_sort_pairs + k_a2_first/k_a2_place",
+                                 "kernel_ms": kern_ms, "reads_per_launch": a.reads, "windows_per_launch": windows, "probe": pp["name"],
+                                 "calls_in_process": a.steps + a.warmup + 1 + (1 if cbp else 0)}})
+        tr = load_pmc_traffic("positions23", reads_per_launch=a.reads)
+        if tr:
+            out["roofline"]["traffic"] = tr.get("bytes_per_launch")
+            out["roofline"]["traffic_source"] = tr.get("source")
 
     elif a.workload == "normalize":
         from aindex_amd import counting

@@ -1158,6 +1158,36 @@ def test_count13_skewed_and_crlf_inputs(ix13):
     assert np.array_equal(ix13.count13(fa), O.count13(m, fa, -1))
 
 
+def test_count13_region_guard_and_foreign_pf(ix13, tmp_path, monkeypatch):
+    """(i) The chunk-region bound of the partitioned counter is no longer a silent guard: with an undersized region
+    (AIX_COUNT13_TEST_REGION) the call fails with AIX_ERR_UNSUPPORTED instead of returning short counts. (ii) A 13-mer handle
+    opened on a .pf that is NOT the all-13-mers one (code -> slot is not a bijection: slots collide and overflow 4^13) counts
+    like the reference, counts[mphf(window)] += 1 for slots < 4^13 (count_kmers13.cpp:147-152), through the adding path."""
+    asc = synth.genome_ascii(5, 60_000)
+    reads = synth.reads_plain(6, asc, 3000, 150, n_rate_ppm=1000).tobytes()
+    monkeypatch.setenv("AIX_COUNT13_TEST_REGION", "100")
+    with pytest.raises(_lib.AixError) as ei:
+        ix13.count13(reads, _lib.FMT_PLAIN)
+    assert ei.value.status == -6
+    monkeypatch.delenv("AIX_COUNT13_TEST_REGION")
+    from pf13 import pf13_path
+    want = O.count13(O.OracleMphf(pf13_path()), reads, 0)
+    assert np.array_equal(ix13.count13(reads, _lib.FMT_PLAIN), want)                 # the handle is fine afterwards
+    rng = np.random.default_rng(11)
+    keys = sorted({bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 13)) for _ in range(6000)})
+    pf = builder.build_pf(keys)
+    path = str(tmp_path / "foreign13.pf")
+    open(path, "wb").write(pf)
+    m = O.OracleMphf(path)
+    with Index.create_13(pf, None) as fx:
+        got = fx.count13(reads, _lib.FMT_PLAIN)
+        want = O.count13(m, reads, 0)
+        assert np.array_equal(got, want) and int(got.sum()) > 0 and int(got.max()) > 1000   # ~6 000 slots shared by every window
+        q = b"".join(keys[:50]) + reads[:13]
+        fx.set_tf_13(got)
+        assert fx.tf_ascii(q).tolist() == [int(want[m.lookup(q[i:i + 13])]) & 0xFFFFFFFF if m.lookup(q[i:i + 13]) < 4 ** 13 else 0 for i in range(0, len(q), 13)]
+
+
 def test_early_exit_walk_on_off(canon_case, ix23, q23):
     """Presence-mask early exit: identical answers in every combination of the three switches, on the canonical
     synthetic index and on the reference-built (non-canonical) golden index."""
