@@ -35,7 +35,8 @@ class Info(C.Structure):
     _fields_ = [("k", C.c_uint32), ("device", C.c_uint32), ("n", C.c_uint64), ("mphf_n", C.c_uint64),
                 ("hash_domain", C.c_uint64), ("seed", C.c_uint64), ("bitpairs", C.c_uint64),
                 ("device_bytes", C.c_uint64), ("canonical_only", C.c_uint32), ("bucket_table", C.c_uint32),
-                ("buckets", C.c_uint64), ("bucket_unfiled_keys", C.c_uint64), ("bucket_lanes", C.c_uint32), ("absence_filter_words", C.c_uint32)]
+                ("buckets", C.c_uint64), ("bucket_unfiled_keys", C.c_uint64), ("bucket_lanes", C.c_uint32), ("absence_filter_words", C.c_uint32),
+                ("minimizer_lines", C.c_uint64), ("minimizer_unfiled_keys", C.c_uint64)]
 
 
 _LIB = None
@@ -58,6 +59,7 @@ SIGNATURES = {
     "aix_index_set_early_exit": (i32, [vp, i32]),
     "aix_index_set_bucket_table": (i32, [vp, i32, i32]),
     "aix_index_set_absence_filter": (i32, [vp, i32]),
+    "aix_index_set_minimizer_table": (i32, [vp, i32]),
     "aix_index_set_tf_13": (i32, [vp, vp]),
     "aix_index_get_tf": (i32, [vp, vp, u64]),
     "aix_index_get_checker": (i32, [vp, vp, u64]),

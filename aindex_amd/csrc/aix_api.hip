@@ -75,6 +75,10 @@ struct aix_index {
     uint32_t bk_lpp = 8;                       // lanes that share one bucket read
     uint64_t bk_unfiled = 0;                   // keys beyond the eighth of their bucket (answered through the MPHF)
     bool bk_enabled = true;
+    BkEntry* mk = nullptr;                     // minimizer-keyed copy of the table for streaming probes (nbm + AIX_MK_CHAIN lines)
+    uint32_t nbm = 0;
+    uint64_t mk_unfiled = 0;
+    bool mk_enabled = true;
     uint64_t* bloom = nullptr;                 // absence filter in front of the table (lookups / coverage)
     uint32_t nbloom = 0;
     bool bloom_enabled = true;
@@ -125,6 +129,8 @@ struct aix_index {
         d.bk_lpp = bk_lpp;
         d.bloom = (d.bk && bloom && bloom_enabled) ? bloom : nullptr;
         d.nbloom = nbloom;
+        d.mk = (d.bk && mk && mk_enabled) ? mk : nullptr;
+        d.nbm = nbm;
         return d;
     }
 };
@@ -256,6 +262,7 @@ static void destroy(aix_index* h) {
     if (h->keys) (void)hipFree(h->keys);
     if (h->bk) (void)hipFree(h->bk);
     if (h->bloom) (void)hipFree(h->bloom);
+    if (h->mk) (void)hipFree(h->mk);
     if (h->tf13_mphf) (void)hipFree(h->tf13_mphf);
     if (h->tf13_code) (void)hipFree(h->tf13_code);
     if (h->perm13) (void)hipFree(h->perm13);
@@ -300,7 +307,25 @@ static int build_bucket_table(aix_index* h, hipStream_t s) {
         h->device_bytes += 8 * nw;
         HIPCHK(hipMemsetAsync(h->bloom, 0, 8 * nw, s));
     }
-    HIPCHK(launch_build_buckets(h->dev().m, h->keys, h->n, h->bk, h->nb, (uint32_t*)fill.p, h->bloom, h->nbloom, s));
+    // minimizer-keyed copy for the streaming consumers (counting, coverage, positions): AIX_MINIMIZER_TABLE=0 skips it
+    bool want_mk = true;
+    if (const char* e = getenv("AIX_MINIMIZER_TABLE")) want_mk = atoi(e) != 0;
+    DevBuf mfill(s);
+    HIPCHK(mfill.alloc_once(4 * (nb + AIX_MK_CHAIN) + 8));
+    HIPCHK(hipMemsetAsync(mfill.p, 0, 4 * (nb + AIX_MK_CHAIN) + 8, s));
+    uint32_t* d_unfiled = (uint32_t*)mfill.p + (nb + AIX_MK_CHAIN);
+    if (want_mk) {
+        HIPCHK(hipMalloc((void**)&h->mk, (nb + AIX_MK_CHAIN) * 8 * sizeof(BkEntry)));
+        h->nbm = (uint32_t)nb;
+        h->device_bytes += (nb + AIX_MK_CHAIN) * 8 * sizeof(BkEntry);
+    }
+    HIPCHK(launch_build_buckets(h->dev().m, h->keys, h->n, h->bk, h->nb, (uint32_t*)fill.p, h->bloom, h->nbloom, h->mk, h->nbm, (uint32_t*)mfill.p, d_unfiled, s));
+    {
+        uint32_t u = 0;
+        HIPCHK(hipMemcpyAsync(&u, d_unfiled, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        h->mk_unfiled = u;
+    }
     // keys left to the MPHF path: sum over buckets of max(fill - 8, 0) (host side: once per open, nb words)
     std::vector<uint32_t> f;
     try { f.resize(nb); } catch (const std::bad_alloc&) { return AIX_ERR_NOMEM; }
@@ -548,6 +573,8 @@ extern "C" int aix_index_info(const aix_index_t* h, aix_info_t* info) {
     info->buckets = h->bk ? h->nb : 0;
     info->bucket_unfiled_keys = h->bk_unfiled;
     info->absence_filter_words = (h->bk && h->bk_enabled && h->bloom && h->bloom_enabled) ? h->nbloom : 0;
+    info->minimizer_lines = (h->bk && h->bk_enabled && h->mk && h->mk_enabled) ? h->nbm : 0;
+    info->minimizer_unfiled_keys = h->mk_unfiled;
     return AIX_OK;
 }
 
@@ -566,6 +593,12 @@ extern "C" int aix_index_set_fingerprint_filter(aix_index_t* h, int enabled) {
 extern "C" int aix_index_set_early_exit(aix_index_t* h, int enabled) {
     if (!h) return AIX_ERR_ARG;
     h->early_exit = enabled != 0;
+    return AIX_OK;
+}
+
+extern "C" int aix_index_set_minimizer_table(aix_index_t* h, int enabled) {
+    if (!h) return AIX_ERR_ARG;
+    h->mk_enabled = enabled != 0;
     return AIX_OK;
 }
 

@@ -414,65 +414,137 @@ __device__ __forceinline__ uint64_t mphf_from_hash(const MphfDev& m, uint64_t a,
 __device__ __forceinline__ uint32_t bucket_of(uint64_t a, uint32_t nb) { return (uint32_t)__umul64hi(a, (uint64_t)nb); }   // nb < 2^32
 
 struct BkRes {
-    uint32_t found, tf, slot, overflow;
+    uint32_t found, tf, slot, overflow, full;
 };
 __device__ __forceinline__ uint32_t bperm(uint32_t src_lane, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v); }
 
-// All 64 lanes of the wave call this together (lanes without a probe pass want = false). LPP consecutive lanes share one
-// probe at a time: in round r the group reads the bucket of its r-th lane, each lane 128 / LPP bytes of the line, so a
-// wave-wide load instruction covers whole 128-byte lines (LPP = 8: eight lines per instruction, fully coalesced) instead of
-// 64 lanes pulling 16 bytes out of 64 different lines eight times over. All loads are issued before the first compare.
-template <int LPP>
-__device__ __forceinline__ BkRes bucket_probe_wave(const BkEntry* __restrict__ bk, uint32_t nb, bool want, uint64_t a, uint64_t code) {
+// Read one 128-byte line of eight {code, tf, slot} entries per probe and compare the codes in it. All 64 lanes of the wave
+// call this together; my_line = the line this lane's probe wants (AIX_BK_NONE: no probe). LPP consecutive lanes share one
+// probe at a time: in round r the group reads the line of its r-th lane, each lane 128 / LPP bytes of it, so a wave-wide load
+// instruction covers whole 128-byte lines (LPP = 8: eight lines per instruction, fully coalesced) instead of 64 lanes pulling
+// 16 bytes out of 64 different lines eight times over. All loads are issued before the first compare.
+// REUSE: consecutive lanes often want the SAME line (streaming windows filed by minimizer): a group whose r-th lane wants the
+// line its (r-1)-th lane wanted keeps the registers of the previous round and issues no load.
+// Returns per lane: found (+ tf, slot), overflow (bit 31 of the line's last entry), full (no empty entry in the line).
+template <int LPP, bool REUSE>
+__device__ __forceinline__ BkRes line_probe_wave(const BkEntry* __restrict__ tab, uint32_t my_line, uint64_t code) {
     constexpr int EPL = 8 / LPP;                                   // entries per lane and round
     const uint32_t lane = __lane_id();
     const uint32_t j = lane & (LPP - 1), gbase = lane & ~(uint32_t)(LPP - 1);
-    const uint32_t my_b = want ? bucket_of(a, nb) : AIX_BK_NONE;
     const uint32_t my_lo = (uint32_t)code, my_hi = (uint32_t)(code >> 32);
     uint4 e[LPP][EPL];
     uint32_t bsrc[LPP];
 #pragma unroll
     for (int r = 0; r < LPP; ++r) {
-        bsrc[r] = LPP == 1 ? my_b : bperm(gbase + r, my_b);
+        bsrc[r] = LPP == 1 ? my_line : bperm(gbase + r, my_line);
+        const bool same = REUSE && r > 0 && bsrc[r] == bsrc[r > 0 ? r - 1 : 0];
 #pragma unroll
-        for (int t = 0; t < EPL; ++t) e[r][t] = make_uint4(0xFFFFFFFFu, AIX_BK_EMPTY_HI, 0u, 0u);
-        // a round in which no group of the wave has a probe (most rounds, when the absence filter has answered nearly every
-        // lane) is skipped as a whole — a scalar branch; otherwise every lane loads (a group without a probe reads bucket 0,
-        // which is always there: cheaper than masking the loads lane by lane)
-        if (__ballot(bsrc[r] != AIX_BK_NONE) != 0ull) {
-            const uint4* p = (const uint4*)(bk + (uint64_t)(bsrc[r] != AIX_BK_NONE ? bsrc[r] : 0u) * 8 + j * EPL);
+        for (int t = 0; t < EPL; ++t) e[r][t] = same ? e[r > 0 ? r - 1 : 0][t] : make_uint4(0xFFFFFFFFu, AIX_BK_EMPTY_HI, 0u, 0u);
+        // a round in which no group of the wave needs a load (no probe, or the line is already in registers) is skipped as a
+        // whole — a scalar branch; otherwise every lane of a loading group loads (a group without a probe reads line 0, which is
+        // always there: cheaper than masking lane by lane), groups that re-use their registers are masked off
+        if (__ballot(bsrc[r] != AIX_BK_NONE && !same) != 0ull) {
+            if (!same) {
+                const uint4* p = (const uint4*)(tab + (uint64_t)(bsrc[r] != AIX_BK_NONE ? bsrc[r] : 0u) * 8 + j * EPL);
 #pragma unroll
-            for (int t = 0; t < EPL; ++t) e[r][t] = p[t];
+                for (int t = 0; t < EPL; ++t) e[r][t] = p[t];
+            }
         }
     }
-    BkRes res{0u, 0u, 0u, 0u};
+    BkRes res{0u, 0u, 0u, 0u, 0u};
 #pragma unroll
     for (int r = 0; r < LPP; ++r) {
         const uint32_t c_lo = LPP == 1 ? my_lo : bperm(gbase + r, my_lo);
         const uint32_t c_hi = LPP == 1 ? my_hi : bperm(gbase + r, my_hi);
         const bool live = bsrc[r] != AIX_BK_NONE;
         uint32_t h_tf = 0, h_slot = 0;
-        bool m = false;
+        bool m = false, hole = false;
 #pragma unroll
         for (int t = 0; t < EPL; ++t) {
             const bool mm = live && e[r][t].x == c_lo && (e[r][t].y & AIX_BK_HI_MASK) == c_hi;
             if (mm) { m = true; h_tf = e[r][t].z; h_slot = e[r][t].w; }
+            hole = hole || (e[r][t].y & AIX_BK_HI_MASK) == AIX_BK_EMPTY_HI;                      // an empty entry: the line is not full
         }
         const bool ov = live && j == (uint32_t)(LPP - 1) && (e[r][EPL - 1].y & AIX_BK_OVERFLOW);    // entry 7 of the line
         if (LPP == 1) {
-            res.found = m; res.tf = h_tf; res.slot = h_slot; res.overflow = ov;
+            res.found = m; res.tf = h_tf; res.slot = h_slot; res.overflow = ov; res.full = live && !hole;
         } else {
-            const uint64_t bal = __ballot(m), balov = __ballot(ov);
+            const uint64_t bal = __ballot(m), balov = __ballot(ov), balhole = __ballot(live && hole);
             const uint32_t grp = (uint32_t)(bal >> gbase) & ((1u << LPP) - 1u);
             const uint32_t ml = gbase + (grp ? (uint32_t)__builtin_ctz(grp) : 0u);
             const uint32_t v_tf = bperm(ml, h_tf), v_slot = bperm(ml, h_slot);
             if (j == (uint32_t)r) {
                 res.found = grp != 0u; res.tf = v_tf; res.slot = v_slot;
                 res.overflow = (uint32_t)(balov >> (gbase + LPP - 1)) & 1u;
+                res.full = live && (((uint32_t)(balhole >> gbase) & ((1u << LPP) - 1u)) == 0u);
             }
         }
     }
     return res;
+}
+
+// verification table keyed by the k-mer's own hash: bucket = mulhi64(a, nb)
+template <int LPP>
+__device__ __forceinline__ BkRes bucket_probe_wave(const BkEntry* __restrict__ bk, uint32_t nb, bool want, uint64_t a, uint64_t code) {
+    return line_probe_wave<LPP, false>(bk, want ? bucket_of(a, nb) : AIX_BK_NONE, code);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Minimizer-keyed copy of the verification table, for STREAMING probes (every window of a read: counting, coverage, the
+// positions probe). Consecutive windows of a sequence share 22 bases and — about seven in a row — their minimizer (the
+// 15-mer of the window with the smallest hash, taken over both strands, so it is the same for a k-mer and its reverse
+// complement). Filing a key under its minimizer instead of its own hash sends those windows to the SAME line: one HBM line
+// per super-k-mer instead of one per window, the rest are hits in registers / L1. A key whose home line is full goes to the
+// next line (up to AIX_MK_CHAIN lines); a key that finds them all full stays out and its home line gets the overflow bit.
+// A probe walks home, home + 1, ... while the lines are full: found = the reference's hit; a line with a free entry and no
+// overflow bit on the home line = the reference's miss; anything else falls back to the hash-keyed table (which files every
+// key). Exactness is the verification in the line, as before.
+// ---------------------------------------------------------------------------------------------
+#define AIX_MK_CHAIN 3
+__device__ __forceinline__ uint32_t mmer_mix(uint32_t x) {        // a bijection of u32: equal hashes <=> equal 15-mers
+    x *= 0x9E3779B1u; x ^= x >> 15; x *= 0x85EBCA77u; x ^= x >> 13;
+    return x;
+}
+// u: 46-bit code, r: its true reverse complement. The 15-mer at position i of u and the one at position 8 - i of r are
+// reverse complements of each other; the smaller of the two is the canonical 15-mer of that position.
+__device__ __forceinline__ uint32_t minimizer23(uint64_t u, uint64_t r) {
+    uint32_t best_h = 0xFFFFFFFFu, best = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const uint32_t f = (uint32_t)(u >> (2 * (8 - i))) & 0x3FFFFFFFu;
+        const uint32_t g = (uint32_t)(r >> (2 * i)) & 0x3FFFFFFFu;
+        const uint32_t c = f < g ? f : g;
+        const uint32_t h = mmer_mix(c);
+        if (h <= best_h) { best_h = h; best = c; }
+    }
+    return best;
+}
+__device__ __forceinline__ uint32_t mk_home(uint32_t minimizer, uint32_t nbm) {
+    uint64_t z = ((uint64_t)minimizer + 1ull) * 0x9E3779B97F4A7C15ULL;
+    z ^= z >> 29; z *= 0xBF58476D1CE4E5B9ULL; z ^= z >> 32;
+    return (uint32_t)__umul64hi(z, (uint64_t)nbm);
+}
+struct MkRes {
+    uint32_t found, tf, slot, undecided;     // undecided: neither found nor proven absent -> the hash-keyed table decides
+};
+template <int LPP>
+__device__ __forceinline__ MkRes mk_probe_wave(const BkEntry* __restrict__ mk, uint32_t nbm, bool want, uint64_t code, uint64_t rc) {
+    const uint32_t home = want ? mk_home(minimizer23(code, rc), nbm) : AIX_BK_NONE;
+    MkRes out{0u, 0u, 0u, 0u};
+    bool open = want;                        // still walking the chain
+    uint32_t ovf_home = 0;
+#pragma unroll 1
+    for (int step = 0; step < AIX_MK_CHAIN; ++step) {
+        if (__ballot(open) == 0ull) break;
+        const BkRes k = line_probe_wave<LPP, true>(mk, open ? home + (uint32_t)step : AIX_BK_NONE, code);
+        if (open) {
+            if (step == 0) ovf_home = k.overflow;
+            if (k.found) { out.found = 1u; out.tf = k.tf; out.slot = k.slot; open = false; }
+            else if (!k.full) { out.undecided = ovf_home; open = false; }          // a free entry ends the chain: absent, unless keys of this home were left out
+        }
+    }
+    if (open) out.undecided = 1u;            // the whole chain was full
+    return out;
 }
 
 }  // namespace aix

@@ -24,6 +24,8 @@ struct IndexDev {
     uint32_t bk_lpp;          // lanes that share one bucket read (8, 4, 2 or 1); launch-time choice
     const uint64_t* bloom;    // 23-mer: absence filter in front of the table (nbloom 64-bit words), nullptr when off
     uint32_t nbloom;
+    const BkEntry* mk;        // 23-mer: minimizer-keyed copy of the table for streaming probes (nbm + AIX_MK_CHAIN lines), nullptr when off
+    uint32_t nbm;
 };
 
 enum LookupMode { MODE_TF = 0, MODE_HASH = 1, MODE_KIDSTRAND = 2, MODE_BOTH = 3, MODE_TOTAL = 4, MODE_LINES = 5 };
@@ -55,7 +57,8 @@ hipError_t launch_set_fingerprints(const MphfDev& m, BvRec* recs_rw, EeRec* ee_r
 // verification table: bk (nb * 8 entries) is initialised and filled from the keys that sit in their own MPHF slot;
 // fill = nb zeroed u32 counters (scratch)
 hipError_t launch_build_buckets(const MphfDev& m, const KeyRec* keys, uint64_t n, BkEntry* bk, uint32_t nb, uint32_t* fill, uint64_t* bloom /* zeroed, nullable */,
-                                uint32_t nbloom, hipStream_t s);
+                                uint32_t nbloom, BkEntry* mk /* nullable */, uint32_t nbm, uint32_t* mfill /* nbm + AIX_MK_CHAIN zeroed words */,
+                                uint32_t* unfiled /* zeroed counter */, hipStream_t s);
 hipError_t launch_scatter23(const MphfDev& m, uint64_t n, uint64_t nslots, const uint8_t* keys_ascii /* or */, const uint64_t* codes, const uint32_t* counts,
                             uint64_t* checker, uint32_t* tf, uint32_t* occupied_bits, uint32_t* conflict, hipStream_t s);
 hipError_t launch_perm13(const MphfDev& m, uint32_t* perm /* [4^13]: code -> mphf index */, hipStream_t s);

@@ -59,13 +59,22 @@ __global__ void __launch_bounds__(kB) k_a2_probe(const IndexDev ix, const uint8_
         const uint64_t want = fwd ? e.code : r;
         uint64_t x0 = w0, x1 = w1, x2 = w2;                                     // forward: the raw bytes of the window
         if (!fwd) ascii23_of_rc(e.code, x0, x1, x2);
-        uint64_t a = 0, b = 0, c = 0;
-        if (probe) jenkins23(x0, x1, x2, ix.m.seed, a, b, c);
         const bool tab = probe && (e.valid || !fwd);                            // the hashed bytes are the ASCII of `want`
-        bool mphf = probe;
-        if (ix.bk) {
-            const BkRes k = bucket_probe_wave<8>(ix.bk, ix.nb, tab, a, want);
+        bool rest = probe;                                                      // windows the hash-keyed path still has to answer
+        if (ix.mk) {                                                            // consecutive windows share their minimizer's line
+            const MkRes k = mk_probe_wave<8>(ix.mk, ix.nbm, tab, want, fwd ? r : e.code);
             if (tab) {
+                if (k.found) { key = k.slot; rest = false; }
+                else if (!k.undecided) rest = false;
+            }
+        }
+        uint64_t a = 0, b = 0, c = 0;
+        if (rest) jenkins23(x0, x1, x2, ix.m.seed, a, b, c);
+        bool mphf = rest;
+        if (ix.bk) {
+            const bool use = rest && tab;
+            const BkRes k = bucket_probe_wave<8>(ix.bk, ix.nb, use, a, want);
+            if (use) {
                 if (k.found) key = k.slot;
                 mphf = !k.found && k.overflow;
             }

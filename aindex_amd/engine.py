@@ -159,9 +159,16 @@ class Index:
         """Blocked Bloom filter in front of the verification table on / off (answers are identical)."""
         check(lib().aix_index_set_absence_filter(self._h, int(enabled)))
 
+    def set_minimizer_table(self, enabled: bool):
+        """Minimizer-keyed copy of the verification table (streaming consumers) on / off (answers are identical)."""
+        check(lib().aix_index_set_minimizer_table(self._h, int(enabled)))
+
     def probe_profile(self) -> dict:
         """What one probe that FINDS its key reads under the current settings (bench.py's roofline accounting)."""
         i = self.info
+        if i["bucket_table"] and i["minimizer_lines"]:
+            return {"name": "minimizer-keyed verification table: one 128-byte line per super-k-mer (about 7 consecutive windows), re-used from registers / L1",
+                    "bytes_per_hit_probe": 128.0, "lines_per_hit_probe": 1.0, "hbm_lines_per_hit_probe": 0.2}
         if i["bucket_table"]:
             return {"name": f"verification table: one 128-byte bucket line per probe ({i['bucket_lanes']} lanes per line)",
                     "bytes_per_hit_probe": 128.0, "lines_per_hit_probe": 1.0}

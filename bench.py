@@ -449,6 +449,8 @@ def apply_ab_switches(ix, a):
         ix.set_bucket_table(not a.no_bucket_table, a.bucket_lanes)
     if a.no_absence_filter:
         ix.set_absence_filter(False)
+    if a.no_minimizer_table:
+        ix.set_minimizer_table(False)
 
 
 def info_flag(ix, name):
@@ -582,6 +584,7 @@ def main():
     ap.add_argument("--no-fingerprint", action="store_true", help="disable the 4-bit fingerprint filter")
     ap.add_argument("--no-early-exit", action="store_true", help="disable the early-exit MPHF walk (presence masks)")
     ap.add_argument("--no-bucket-table", action="store_true", help="switch the verification table off (every probe through the MPHF records + key records)")
+    ap.add_argument("--no-minimizer-table", action="store_true", help="streaming consumers (count23, coverage, positions) probe the hash-keyed table: one HBM line per window")
     ap.add_argument("--no-absence-filter", action="store_true", help="switch the Bloom filter in front of the verification table off")
     ap.add_argument("--bucket-lanes", type=int, default=0, choices=[0, 1, 2, 4, 8], help="lanes that share one bucket read (0: the library's default)")
     ap.add_argument("--gpu-builder", action="store_true", help="build the MPHF on the GPU (parallel peeling) instead of the host")

@@ -62,6 +62,8 @@ typedef struct {
     uint64_t bucket_unfiled_keys; /* keys beyond the eighth of their bucket (MPHF path)        */
     uint32_t bucket_lanes;    /* lanes that share one bucket read (8, 4, 2 or 1)               */
     uint32_t absence_filter_words; /* 64-bit words of the absence filter in front of the table (0: off) */
+    uint64_t minimizer_lines;     /* 128-byte lines of the minimizer-keyed copy of the table (0: off)   */
+    uint64_t minimizer_unfiled_keys; /* keys whose chain of lines was full (answered by the hash-keyed table) */
 } aix_info_t;
 
 const char* aix_version(void);
@@ -113,6 +115,12 @@ int aix_index_set_bucket_table(aix_index_t* h, int enabled, int lanes);
  * 8-byte read that answers most absent keys before the table is touched (AIX_BLOOM_BITS bits per key at open, default 16,
  * 0 = none). Off / on for A/B measurements; answers are identical. */
 int aix_index_set_absence_filter(aix_index_t* h, int enabled);
+/* Minimizer-keyed copy of the verification table, used by the STREAMING consumers (aix_count23_fixed*, aix_coverage_batch*,
+ * aix_positions_*): every key is also filed under the minimizer of its 23-mer (the 15-mer with the smallest hash over both
+ * strands), so the ~7 consecutive windows of a sequence that share a minimizer read the SAME 128-byte line — one HBM line
+ * per super-k-mer instead of one per window. Built at open unless AIX_MINIMIZER_TABLE=0; off / on for A/B measurements;
+ * answers are identical (verification in the line; undecided probes fall back to the hash-keyed table). */
+int aix_index_set_minimizer_table(aix_index_t* h, int enabled);
 /* replace the tf table of a 13-mer handle (u64[4^13], mphf order, HOST pointer) */
 int aix_index_set_tf_13(aix_index_t* h, const uint64_t* tf);
 /* copy tf out (HOST pointer): 23 -> u32[n]; 13 -> u64[4^13] in mphf order

@@ -1344,10 +1344,12 @@ def test_count23_histogram_backend_equals_atomics_and_oracle(canon_case, small23
                         monkeypatch.delenv("AIX_COUNT23_PIECE", raising=False)
                     else:
                         monkeypatch.setenv("AIX_COUNT23_PIECE", piece)
-                    for bk in (True, False):
+                    for bk, mk in ((True, True), (True, False), (False, False)):
                         ix.set_bucket_table(bk)
-                        assert np.array_equal(ix.count23_fixed(buf, _lib.FMT_PLAIN, mode), want), (mode, piece, bk)
+                        ix.set_minimizer_table(mk)
+                        assert np.array_equal(ix.count23_fixed(buf, _lib.FMT_PLAIN, mode), want), (mode, piece, bk, mk)
                 ix.set_bucket_table(True)
+                ix.set_minimizer_table(True)
                 monkeypatch.delenv("AIX_COUNT23_PIECE", raising=False)
                 t = torch.frombuffer(bytearray(buf), dtype=torch.uint8).cuda()
                 acc = torch.zeros(ix.n, dtype=torch.int32, device="cuda")
@@ -1401,10 +1403,14 @@ def test_bucket_table_every_consumer_on_off_and_overflowing(canon_case, small23_
                 for lanes in (8, 4, 2, 1):
                     ix.set_bucket_table(True, lanes)
                     ix.set_absence_filter(lanes != 4)                        # the absence filter in front of the table: on, and off once
-                    assert ix.info["bucket_lanes"] == lanes and (ix.info["absence_filter_words"] > 0) == (lanes != 4)
+                    ix.set_minimizer_table(lanes != 2)                       # the minimizer-keyed copy for the streaming consumers: on, and off once
+                    info = ix.info
+                    assert info["bucket_lanes"] == lanes and (info["absence_filter_words"] > 0) == (lanes != 4) and (info["minimizer_lines"] > 0) == (lanes != 2)
                     got = answers(ix)
                     for k, v in base.items():
                         assert np.array_equal(got[k], v), (load, pre, lanes, k)
+                if load == "8" and pre == prefix:
+                    assert info["minimizer_unfiled_keys"] > ix.n // 20       # chains of full lines: the fall-back to the hash-keyed table runs
     monkeypatch.setenv("AIX_BUCKET_TABLE", "0")                              # not built at all: the MPHF path alone
     with Index.open_23(prefix + ".pf", prefix + ".tf.bin", prefix + ".kmers.bin") as ix:
         assert ix.info["bucket_table"] == 0 and ix.info["buckets"] == 0
