@@ -1182,7 +1182,7 @@ def test_count13_region_guard_and_foreign_pf(ix13, tmp_path, monkeypatch):
     with Index.create_13(pf, None) as fx:
         got = fx.count13(reads, _lib.FMT_PLAIN)
         want = O.count13(m, reads, 0)
-        assert np.array_equal(got, want) and int(got.sum()) > 0 and int(got.max()) > 1000   # ~6 000 slots shared by every window
+        assert np.array_equal(got, want) and int(got.sum()) > 0 and int(got.max()) > 100 and int(np.count_nonzero(got)) <= 6001   # ~6 000 slots shared by every window
         q = b"".join(keys[:50]) + reads[:13]
         fx.set_tf_13(got)
         assert fx.tf_ascii(q).tolist() == [int(want[m.lookup(q[i:i + 13])]) & 0xFFFFFFFF if m.lookup(q[i:i + 13]) < 4 ** 13 else 0 for i in range(0, len(q), 13)]
