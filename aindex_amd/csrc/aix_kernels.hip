@@ -83,7 +83,7 @@ __device__ __forceinline__ Probe probe23_wave(const IndexDev& ix, bool want, uin
     bool rest = want;                                           // lanes the hash-keyed path still has to answer
     if (ix.mk) {                                                // streaming kernels: the minimizer-keyed table first (no Jenkins hash at all)
         const bool use = want && filters;
-        const MkRes k = mk_probe_wave<LPP>(ix.mk, ix.nbm, use, code, revcomp(code, 23));
+        const MkRes k = mk_probe_wave<1>(ix.mk, ix.nbm, use, code, revcomp(code, 23));   // every lane its own line: neighbours want the same one, the loads coalesce
         if (use) {
             r.lines = 1048576;
             if (k.found) { r.found = true; r.tf = k.tf; r.slot = k.slot; rest = false; }

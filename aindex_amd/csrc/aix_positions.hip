@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(kB) k_a2_probe(const IndexDev ix, const uint8_
         const bool tab = probe && (e.valid || !fwd);                            // the hashed bytes are the ASCII of `want`
         bool rest = probe;                                                      // windows the hash-keyed path still has to answer
         if (ix.mk) {                                                            // consecutive windows share their minimizer's line
-            const MkRes k = mk_probe_wave<8>(ix.mk, ix.nbm, tab, want, fwd ? r : e.code);
+            const MkRes k = mk_probe_wave<1>(ix.mk, ix.nbm, tab, want, fwd ? r : e.code);
             if (tab) {
                 if (k.found) { key = k.slot; rest = false; }
                 else if (!k.undecided) rest = false;

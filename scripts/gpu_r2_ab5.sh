@@ -4,7 +4,7 @@ set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r2ab5; mkdir -p $O; cd $R
 step () { echo "== $1 $(date +%T)" | tee -a $O/progress.txt; }
 step "targeted tests"
-timeout -k 10 1000 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -m gpu -x -q -k "bucket or histogram or fuzz_queries or inconsistent or coverage or positions_fill or count23 or edge_cases or count13_region or q23" > $O/pytest_gpu.log 2>&1; rc=$?; tail -5 $O/pytest_gpu.log
+timeout -k 10 1000 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -m gpu -x -q -k "bucket or histogram or count23_fixed or positions_fill_equals" > $O/pytest_gpu.log 2>&1; rc=$?; tail -5 $O/pytest_gpu.log
 [ $rc -eq 0 ] || { grep -n "^E " $O/pytest_gpu.log | head -20; exit 3; }
 B="--no-cpu-baseline --no-secondary --no-gather-probe --steps 5 --warmup 1"
 run () { n=$1; shift; timeout -k 10 400 python bench.py "$@" > $O/$n.json 2> $O/$n.err || { echo "$n failed"; tail -8 $O/$n.err; return 1; }
