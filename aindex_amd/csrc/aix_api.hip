@@ -307,18 +307,28 @@ static int build_bucket_table(aix_index* h, hipStream_t s) {
         h->device_bytes += 8 * nw;
         HIPCHK(hipMemsetAsync(h->bloom, 0, 8 * nw, s));
     }
-    // minimizer-keyed copy for the streaming consumers (counting, coverage, positions): AIX_MINIMIZER_TABLE=0 skips it
-    bool want_mk = true;
+    // minimizer-keyed copy for the streaming consumers (counting, coverage, positions): built only on request
+    // (AIX_MINIMIZER_TABLE=1). Measured and NOT adopted as the default: it does cut the HBM lines per window ~5x, but once a
+    // probe costs one line those kernels are bound by their instruction stream (encode + canonical form + hash / minimizer +
+    // compare: ~60 % of the VALU peak), and the minimizer walk costs more instructions than the Jenkins hash it replaces —
+    // count23 47.7 ms against 43.5 ms per 10 M reads, coverage 34.8 against 31.8 ms, positions 45.9 against 43.2 ms.
+    bool want_mk = false;
     if (const char* e = getenv("AIX_MINIMIZER_TABLE")) want_mk = atoi(e) != 0;
-    DevBuf mfill(s);
-    HIPCHK(mfill.alloc_once(4 * (nb + AIX_MK_CHAIN) + 8));
-    HIPCHK(hipMemsetAsync(mfill.p, 0, 4 * (nb + AIX_MK_CHAIN) + 8, s));
-    uint32_t* d_unfiled = (uint32_t*)mfill.p + (nb + AIX_MK_CHAIN);
+    uint64_t nbm = 0;
     if (want_mk) {
-        HIPCHK(hipMalloc((void**)&h->mk, (nb + AIX_MK_CHAIN) * 8 * sizeof(BkEntry)));
-        h->nbm = (uint32_t)nb;
-        h->device_bytes += (nb + AIX_MK_CHAIN) * 8 * sizeof(BkEntry);
+        double mload = 3.0;                                                    // keys per 8-entry line of the minimizer-keyed copy (groups are clumpy)
+        if (const char* e = getenv("AIX_MINIMIZER_LOAD")) { const double v = atof(e); if (v >= 0.25 && v <= 8.0) mload = v; }
+        nbm = (uint64_t)((double)h->n / mload) + 1;
+        if (nbm > 0xFFFFFFF0ull) nbm = 0xFFFFFFF0ull;
+        HIPCHK(hipMalloc((void**)&h->mk, (nbm + AIX_MK_CHAIN) * 8 * sizeof(BkEntry)));
+        h->nbm = (uint32_t)nbm;
+        h->device_bytes += (nbm + AIX_MK_CHAIN) * 8 * sizeof(BkEntry);
     }
+    DevBuf mfill(s);
+    const uint64_t mfill_words = nbm + AIX_MK_CHAIN;
+    HIPCHK(mfill.alloc_once(4 * mfill_words + 8));
+    HIPCHK(hipMemsetAsync(mfill.p, 0, 4 * mfill_words + 8, s));
+    uint32_t* d_unfiled = (uint32_t*)mfill.p + mfill_words;
     HIPCHK(launch_build_buckets(h->dev().m, h->keys, h->n, h->bk, h->nb, (uint32_t*)fill.p, h->bloom, h->nbloom, h->mk, h->nbm, (uint32_t*)mfill.p, d_unfiled, s));
     {
         uint32_t u = 0;
@@ -850,7 +860,8 @@ extern "C" int aix_count23_fixed_dev(aix_index_t* h, const char* d_plain, uint64
     const IndexDev d = h->dev();
     for (uint64_t first = 0; first < nwin; first += pw) {
         const uint64_t w = std::min(pw, nwin - first);
-        HIPCHK(launch_probe23_slots(d, (const uint8_t*)d_plain + first, w + 22, canon_mode, slots, s));
+        if (d.mk) HIPCHK(launch_stream23_slots(d, (const uint8_t*)d_plain + first, w + 22, canon_mode, slots, s));   // 32 consecutive windows per lane
+        else HIPCHK(launch_probe23_slots(d, (const uint8_t*)d_plain + first, w + 22, canon_mode, slots, s));
         HIPCHK(launch_histogram_slots(slots, w, h->work13, d_tf_out, h->n, s));
     }
     uint32_t dropped = 0;

@@ -507,19 +507,25 @@ __device__ __forceinline__ uint32_t mmer_mix(uint32_t x) {        // a bijection
 }
 // u: 46-bit code, r: its true reverse complement. The 15-mer at position i of u and the one at position 8 - i of r are
 // reverse complements of each other; the smaller of the two is the canonical 15-mer of that position.
+// Returns the HASH of the minimizer (mmer_mix is a bijection, so it names the 15-mer just as well and saves selecting it).
 __device__ __forceinline__ uint32_t minimizer23(uint64_t u, uint64_t r) {
-    uint32_t best_h = 0xFFFFFFFFu, best = 0;
+    uint32_t best_h = 0xFFFFFFFFu;
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
         const uint32_t f = (uint32_t)(u >> (2 * (8 - i))) & 0x3FFFFFFFu;
         const uint32_t g = (uint32_t)(r >> (2 * i)) & 0x3FFFFFFFu;
-        const uint32_t c = f < g ? f : g;
-        const uint32_t h = mmer_mix(c);
-        if (h <= best_h) { best_h = h; best = c; }
+        const uint32_t h = mmer_mix(f < g ? f : g);
+        best_h = h < best_h ? h : best_h;
     }
-    return best;
+    return best_h;
 }
-__device__ __forceinline__ uint32_t mk_home(uint32_t minimizer, uint32_t nbm) {
+// reverse complement of a 15-mer code (30 bits)
+__device__ __forceinline__ uint32_t revcomp15(uint32_t x) {
+    uint32_t y = __builtin_bitreverse32(x);
+    y = ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
+    return (~y) >> 2;
+}
+__device__ __forceinline__ uint32_t mk_home(uint32_t minimizer, uint32_t nbm) {      // the minimum of nine hashes is skewed towards 0: mixed again
     uint64_t z = ((uint64_t)minimizer + 1ull) * 0x9E3779B97F4A7C15ULL;
     z ^= z >> 29; z *= 0xBF58476D1CE4E5B9ULL; z ^= z >> 32;
     return (uint32_t)__umul64hi(z, (uint64_t)nbm);

@@ -74,6 +74,8 @@ hipError_t launch_count13_partitioned(const uint8_t* buf, uint64_t len, void* wo
 // count23 without global atomics: tf_out[slot] += occurrences of slot in the stream (slots < 2^26, 0xFFFFFFFF = skip)
 hipError_t launch_histogram_slots(const uint32_t* d_slots, uint64_t nslots, void* workspace /* count13_workspace_bytes(nslots + 12) */, uint32_t* tf_out,
                                   uint64_t n, hipStream_t s);
+// the same slot stream from the minimizer-keyed table (aix_stream23.hip): a lane owns 32 consecutive windows; needs ix.mk
+hipError_t launch_stream23_slots(const IndexDev& ix, const uint8_t* buf, uint64_t len, int canon_mode, uint32_t* slots /* [len - 22] */, hipStream_t s);
 hipError_t launch_probe23_slots(const IndexDev& ix, const uint8_t* buf, uint64_t len, int canon_mode, uint32_t* slots /* [len - 22] */, hipStream_t s);
 hipError_t launch_scatter13_to_mphf(const uint32_t* perm, const unsigned long long* table_code, uint64_t* out_mphf, int add, hipStream_t s);
 hipError_t launch_perm13_check(const uint32_t* perm, uint32_t* bits /* 4^13 / 32 zeroed words */, uint32_t* bad /* zeroed */, hipStream_t s);

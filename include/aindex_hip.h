@@ -118,8 +118,9 @@ int aix_index_set_absence_filter(aix_index_t* h, int enabled);
 /* Minimizer-keyed copy of the verification table, used by the STREAMING consumers (aix_count23_fixed*, aix_coverage_batch*,
  * aix_positions_*): every key is also filed under the minimizer of its 23-mer (the 15-mer with the smallest hash over both
  * strands), so the ~7 consecutive windows of a sequence that share a minimizer read the SAME 128-byte line — one HBM line
- * per super-k-mer instead of one per window. Built at open unless AIX_MINIMIZER_TABLE=0; off / on for A/B measurements;
- * answers are identical (verification in the line; undecided probes fall back to the hash-keyed table). */
+ * per super-k-mer instead of one per window. EXPERIMENTAL: built at open only with AIX_MINIMIZER_TABLE=1 (measured slower than
+ * the hash-keyed table on MI355X: those kernels are instruction-bound once a probe costs one line); off / on per
+ * handle for A/B measurements; answers are identical (verification in the line; undecided probes fall back to the hash-keyed table). */
 int aix_index_set_minimizer_table(aix_index_t* h, int enabled);
 /* replace the tf table of a 13-mer handle (u64[4^13], mphf order, HOST pointer) */
 int aix_index_set_tf_13(aix_index_t* h, const uint64_t* tf);

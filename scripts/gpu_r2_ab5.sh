@@ -13,20 +13,18 @@ import json; d=json.load(open("$O/$n.json")); r=d["roofline"]
 print("%-28s %10.4g %s  kernel_ms %.3f  frac %.3f" % ("$n", d["value"], d["unit"], r["kernel_ms"], r["frac"]))
 PY
 }
-run count23_mk --workload count23 --reads 10000000 $B || exit 5
+AIX_MINIMIZER_TABLE=1 run count23_mk --workload count23 --reads 10000000 $B || exit 5
 run count23_nomk --workload count23 --reads 10000000 --no-minimizer-table $B || exit 5
-run cov_mk --workload coverage23 --seqs 100000 $B || exit 5
+AIX_MINIMIZER_TABLE=1 run cov_mk --workload coverage23 --seqs 100000 $B || exit 5
 run cov_nomk --workload coverage23 --seqs 100000 --no-minimizer-table $B || exit 5
-run pos_mk --workload positions23 --reads 5000000 $B || exit 5
+AIX_MINIMIZER_TABLE=1 run pos_mk --workload positions23 --reads 5000000 $B || exit 5
 run pos_nomk --workload positions23 --reads 5000000 --no-minimizer-table $B || exit 5
-run qrand --workload lookup23 $B || exit 5
+AIX_MINIMIZER_TABLE=1 AIX_MINIMIZER_LOAD=2 run count23_mk_load2 --workload count23 --reads 10000000 $B || exit 5
+AIX_MINIMIZER_TABLE=1 AIX_MINIMIZER_LOAD=4 run count23_mk_load4 --workload count23 --reads 10000000 $B || exit 5
 grep -h "index:" $O/count23_mk.err | tail -1
-python - <<PY
-import json; d=json.load(open("$O/qrand.json")); print({k: d["config"][k] for k in ("buckets", "bucket_unfiled_keys", "index_hbm_bytes")})
-PY
 export TMPDIR=/tmp; cd /tmp
 step "rocprofv3 kernel trace: count23"
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c23 -- python3 $R/bench.py --workload count23 --reads 10000000 --steps 5 --warmup 1 --no-cpu-baseline --no-gather-probe > $O/prof_c23.out 2> $O/prof_c23.err || exit 8
+AIX_MINIMIZER_TABLE=1 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c23 -- python3 $R/bench.py --workload count23 --reads 10000000 --steps 5 --warmup 1 --no-cpu-baseline --no-gather-probe > $O/prof_c23.out 2> $O/prof_c23.err || exit 8
 f=$(find $O/prof_c23 -name "*kernel_stats.csv" | head -1); python - <<PY
 import csv
 for i, r in enumerate(csv.DictReader(open("$f"))):

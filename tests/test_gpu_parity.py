@@ -1329,9 +1329,11 @@ def test_count23_histogram_backend_equals_atomics_and_oracle(canon_case, small23
     reads = synth.reads_plain(41, asc, 4000, 150, rc_fraction_half=True, n_rate_ppm=1000).tobytes()
     noisy = bytes(asc[5000:9000]).lower() + b"\n" + bytes(asc[100:400]).replace(b"C", b"R", 2) + b"~U" + bytes(asc[900:1300]) + b"\n" + reads[:60_000]
     gold_reads = open(small23_prefix + ".reads", "rb").read()
-    cases = [(canon_case["ix"], orc, reads), (canon_case["ix"], orc, noisy)]
-    with Index.open_23(small23_prefix + ".pf", small23_prefix + ".tf.bin", small23_prefix + ".kmers.bin") as gix:
-        cases.append((gix, O.OracleIndex23.from_prefix(small23_prefix), gold_reads))
+    monkeypatch.setenv("AIX_MINIMIZER_TABLE", "1")                          # built for the handles opened here (experimental copy)
+    prefix = canon_case["prefix"]
+    with Index.open_23(small23_prefix + ".pf", small23_prefix + ".tf.bin", small23_prefix + ".kmers.bin") as gix, \
+            Index.open_23(prefix + ".pf", prefix + ".tf.bin", prefix + ".kmers.bin") as cix:
+        cases = [(cix, orc, reads), (cix, orc, noisy), (gix, O.OracleIndex23.from_prefix(small23_prefix), gold_reads)]
         for ix, o, buf in cases:
             for mode in (0, 1, 2):
                 want = o.count23_fixed(buf, False, mode)
@@ -1382,6 +1384,7 @@ def test_bucket_table_every_consumer_on_off_and_overflowing(canon_case, small23_
                 "cov": np.concatenate(ix.coverage(seqs, 0)), "c0": ix.count23_fixed(noisy, _lib.FMT_PLAIN, 0), "c1": ix.count23_fixed(noisy, _lib.FMT_PLAIN, 1),
                 "c2": ix.count23_fixed(reads, _lib.FMT_PLAIN, 2), "ind": ind, "pos": pos}
 
+    monkeypatch.setenv("AIX_MINIMIZER_TABLE", "1")                          # the experimental minimizer-keyed copy is built too
     for load in (None, "8", "0.5"):
         if load is None:
             monkeypatch.delenv("AIX_BUCKET_LOAD", raising=False)
