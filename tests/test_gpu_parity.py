@@ -1388,8 +1388,10 @@ def test_bucket_table_every_consumer_on_off_and_overflowing(canon_case, small23_
     for load in (None, "8", "0.5"):
         if load is None:
             monkeypatch.delenv("AIX_BUCKET_LOAD", raising=False)
+            monkeypatch.delenv("AIX_MINIMIZER_LOAD", raising=False)
         else:
             monkeypatch.setenv("AIX_BUCKET_LOAD", load)
+            monkeypatch.setenv("AIX_MINIMIZER_LOAD", load)
         for pre, o in ((prefix, orc), (small23_prefix, None)):
             with Index.open_23(pre + ".pf", pre + ".tf.bin", pre + ".kmers.bin") as ix:
                 info = ix.info
