@@ -75,7 +75,7 @@ struct aix_index {
     uint32_t bk_lpp = 8;                       // lanes that share one bucket read
     uint64_t bk_unfiled = 0;                   // keys beyond the eighth of their bucket (answered through the MPHF)
     bool bk_enabled = true;
-    BkEntry* mk = nullptr;                     // minimizer-keyed copy of the table for streaming probes (nbm + AIX_MK_CHAIN lines)
+    BkEntry* mk = nullptr;                     // minimizer-keyed copy of the table for the streaming counter (nbm buckets of 16 entries)
     uint32_t nbm = 0;
     uint64_t mk_unfiled = 0;
     bool mk_enabled = true;
@@ -316,16 +316,16 @@ static int build_bucket_table(aix_index* h, hipStream_t s) {
     if (const char* e = getenv("AIX_MINIMIZER_TABLE")) want_mk = atoi(e) != 0;
     uint64_t nbm = 0;
     if (want_mk) {
-        double mload = 3.0;                                                    // keys per 8-entry line of the minimizer-keyed copy (groups are clumpy)
-        if (const char* e = getenv("AIX_MINIMIZER_LOAD")) { const double v = atof(e); if (v >= 0.25 && v <= 8.0) mload = v; }
+        double mload = 6.0;                                                    // keys per 16-entry bucket of the minimizer-keyed copy (the groups of one minimizer arrive together)
+        if (const char* e = getenv("AIX_MINIMIZER_LOAD")) { const double v = atof(e); if (v >= 0.5 && v <= 16.0) mload = v; }
         nbm = (uint64_t)((double)h->n / mload) + 1;
         if (nbm > 0xFFFFFFF0ull) nbm = 0xFFFFFFF0ull;
-        HIPCHK(hipMalloc((void**)&h->mk, (nbm + AIX_MK_CHAIN) * 8 * sizeof(BkEntry)));
+        HIPCHK(hipMalloc((void**)&h->mk, nbm * AIX_MK_ENTRIES * sizeof(BkEntry)));
         h->nbm = (uint32_t)nbm;
-        h->device_bytes += (nbm + AIX_MK_CHAIN) * 8 * sizeof(BkEntry);
+        h->device_bytes += nbm * AIX_MK_ENTRIES * sizeof(BkEntry);
     }
     DevBuf mfill(s);
-    const uint64_t mfill_words = nbm + AIX_MK_CHAIN;
+    const uint64_t mfill_words = nbm + 1;
     HIPCHK(mfill.alloc_once(4 * mfill_words + 8));
     HIPCHK(hipMemsetAsync(mfill.p, 0, 4 * mfill_words + 8, s));
     uint32_t* d_unfiled = (uint32_t*)mfill.p + mfill_words;
@@ -860,7 +860,10 @@ extern "C" int aix_count23_fixed_dev(aix_index_t* h, const char* d_plain, uint64
     const IndexDev d = h->dev();
     for (uint64_t first = 0; first < nwin; first += pw) {
         const uint64_t w = std::min(pw, nwin - first);
-        if (d.mk) HIPCHK(launch_stream23_slots(d, (const uint8_t*)d_plain + first, w + 22, canon_mode, slots, s));   // 32 consecutive windows per lane
+        if (d.mk) {                                                            // 32 consecutive windows per lane; word 1 of the workspace = "undecided windows" flag
+            HIPCHK(hipMemsetAsync((uint32_t*)h->work13 + 1, 0, 4, s));
+            HIPCHK(launch_stream23_slots(d, (const uint8_t*)d_plain + first, w + 22, canon_mode, slots, (uint32_t*)h->work13 + 1, s));
+        }
         else HIPCHK(launch_probe23_slots(d, (const uint8_t*)d_plain + first, w + 22, canon_mode, slots, s));
         HIPCHK(launch_histogram_slots(slots, w, h->work13, d_tf_out, h->n, s));
     }

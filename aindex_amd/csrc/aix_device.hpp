@@ -423,10 +423,8 @@ __device__ __forceinline__ uint32_t bperm(uint32_t src_lane, uint32_t v) { retur
 // probe at a time: in round r the group reads the line of its r-th lane, each lane 128 / LPP bytes of it, so a wave-wide load
 // instruction covers whole 128-byte lines (LPP = 8: eight lines per instruction, fully coalesced) instead of 64 lanes pulling
 // 16 bytes out of 64 different lines eight times over. All loads are issued before the first compare.
-// REUSE: consecutive lanes often want the SAME line (streaming windows filed by minimizer): a group whose r-th lane wants the
-// line its (r-1)-th lane wanted keeps the registers of the previous round and issues no load.
 // Returns per lane: found (+ tf, slot), overflow (bit 31 of the line's last entry), full (no empty entry in the line).
-template <int LPP, bool REUSE>
+template <int LPP>
 __device__ __forceinline__ BkRes line_probe_wave(const BkEntry* __restrict__ tab, uint32_t my_line, uint64_t code) {
     constexpr int EPL = 8 / LPP;                                   // entries per lane and round
     const uint32_t lane = __lane_id();
@@ -437,18 +435,15 @@ __device__ __forceinline__ BkRes line_probe_wave(const BkEntry* __restrict__ tab
 #pragma unroll
     for (int r = 0; r < LPP; ++r) {
         bsrc[r] = LPP == 1 ? my_line : bperm(gbase + r, my_line);
-        const bool same = REUSE && r > 0 && bsrc[r] == bsrc[r > 0 ? r - 1 : 0];
 #pragma unroll
-        for (int t = 0; t < EPL; ++t) e[r][t] = same ? e[r > 0 ? r - 1 : 0][t] : make_uint4(0xFFFFFFFFu, AIX_BK_EMPTY_HI, 0u, 0u);
-        // a round in which no group of the wave needs a load (no probe, or the line is already in registers) is skipped as a
-        // whole — a scalar branch; otherwise every lane of a loading group loads (a group without a probe reads line 0, which is
-        // always there: cheaper than masking lane by lane), groups that re-use their registers are masked off
-        if (__ballot(bsrc[r] != AIX_BK_NONE && !same) != 0ull) {
-            if (!same) {
-                const uint4* p = (const uint4*)(tab + (uint64_t)(bsrc[r] != AIX_BK_NONE ? bsrc[r] : 0u) * 8 + j * EPL);
+        for (int t = 0; t < EPL; ++t) e[r][t] = make_uint4(0xFFFFFFFFu, AIX_BK_EMPTY_HI, 0u, 0u);
+        // a round in which no group of the wave has a probe (most rounds, when the absence filter has answered nearly every
+        // lane) is skipped as a whole — a scalar branch; otherwise every lane loads (a group without a probe reads line 0,
+        // which is always there: cheaper than masking the loads lane by lane)
+        if (__ballot(bsrc[r] != AIX_BK_NONE) != 0ull) {
+            const uint4* p = (const uint4*)(tab + (uint64_t)(bsrc[r] != AIX_BK_NONE ? bsrc[r] : 0u) * 8 + j * EPL);
 #pragma unroll
-                for (int t = 0; t < EPL; ++t) e[r][t] = p[t];
-            }
+            for (int t = 0; t < EPL; ++t) e[r][t] = p[t];
         }
     }
     BkRes res{0u, 0u, 0u, 0u, 0u};
@@ -486,28 +481,32 @@ __device__ __forceinline__ BkRes line_probe_wave(const BkEntry* __restrict__ tab
 // verification table keyed by the k-mer's own hash: bucket = mulhi64(a, nb)
 template <int LPP>
 __device__ __forceinline__ BkRes bucket_probe_wave(const BkEntry* __restrict__ bk, uint32_t nb, bool want, uint64_t a, uint64_t code) {
-    return line_probe_wave<LPP, false>(bk, want ? bucket_of(a, nb) : AIX_BK_NONE, code);
+    return line_probe_wave<LPP>(bk, want ? bucket_of(a, nb) : AIX_BK_NONE, code);
 }
 
 // ---------------------------------------------------------------------------------------------
-// Minimizer-keyed copy of the verification table, for STREAMING probes (every window of a read: counting, coverage, the
-// positions probe). Consecutive windows of a sequence share 22 bases and — about seven in a row — their minimizer (the
-// 15-mer of the window with the smallest hash, taken over both strands, so it is the same for a k-mer and its reverse
-// complement). Filing a key under its minimizer instead of its own hash sends those windows to the SAME line: one HBM line
-// per super-k-mer instead of one per window, the rest are hits in registers / L1. A key whose home line is full goes to the
-// next line (up to AIX_MK_CHAIN lines); a key that finds them all full stays out and its home line gets the overflow bit.
-// A probe walks home, home + 1, ... while the lines are full: found = the reference's hit; a line with a free entry and no
-// overflow bit on the home line = the reference's miss; anything else falls back to the hash-keyed table (which files every
-// key). Exactness is the verification in the line, as before.
+// Minimizer-keyed copy of the verification table, for the STREAMING counter (aix_stream23.hip: every window of a read).
+// Consecutive windows of a sequence share 22 bases and — about seven in a row — their minimizer (the 15-mer of the window with
+// the smallest hash, taken over both strands, so it is the same for a k-mer and its reverse complement). Filing a key under
+// its minimizer instead of its own hash sends those windows to the SAME bucket: one HBM read per super-k-mer instead of one
+// per window. A bucket is 16 entries = two 128-byte lines read together (the keys of one minimizer arrive in groups, so the
+// buckets fill unevenly); a key that finds its bucket full stays out and the bucket's last entry gets the overflow bit: a
+// probe that does not find its code in such a bucket is UNDECIDED and is settled by the MPHF path.
 // ---------------------------------------------------------------------------------------------
-#define AIX_MK_CHAIN 3
+#define AIX_MK_ENTRIES 16
 __device__ __forceinline__ uint32_t mmer_mix(uint32_t x) {        // a bijection of u32: equal hashes <=> equal 15-mers
     x *= 0x9E3779B1u; x ^= x >> 15; x *= 0x85EBCA77u; x ^= x >> 13;
     return x;
 }
+// reverse complement of a 15-mer code (30 bits)
+__device__ __forceinline__ uint32_t revcomp15(uint32_t x) {
+    uint32_t y = __builtin_bitreverse32(x);
+    y = ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
+    return (~y) >> 2;
+}
 // u: 46-bit code, r: its true reverse complement. The 15-mer at position i of u and the one at position 8 - i of r are
-// reverse complements of each other; the smaller of the two is the canonical 15-mer of that position.
-// Returns the HASH of the minimizer (mmer_mix is a bijection, so it names the 15-mer just as well and saves selecting it).
+// reverse complements of each other; the smaller of the two is the canonical 15-mer of that position. Returns the HASH of the
+// minimizer (mmer_mix is a bijection, so it names the 15-mer just as well).
 __device__ __forceinline__ uint32_t minimizer23(uint64_t u, uint64_t r) {
     uint32_t best_h = 0xFFFFFFFFu;
 #pragma unroll
@@ -519,38 +518,10 @@ __device__ __forceinline__ uint32_t minimizer23(uint64_t u, uint64_t r) {
     }
     return best_h;
 }
-// reverse complement of a 15-mer code (30 bits)
-__device__ __forceinline__ uint32_t revcomp15(uint32_t x) {
-    uint32_t y = __builtin_bitreverse32(x);
-    y = ((y >> 1) & 0x55555555u) | ((y & 0x55555555u) << 1);
-    return (~y) >> 2;
-}
 __device__ __forceinline__ uint32_t mk_home(uint32_t minimizer, uint32_t nbm) {      // the minimum of nine hashes is skewed towards 0: mixed again
     uint64_t z = ((uint64_t)minimizer + 1ull) * 0x9E3779B97F4A7C15ULL;
     z ^= z >> 29; z *= 0xBF58476D1CE4E5B9ULL; z ^= z >> 32;
     return (uint32_t)__umul64hi(z, (uint64_t)nbm);
-}
-struct MkRes {
-    uint32_t found, tf, slot, undecided;     // undecided: neither found nor proven absent -> the hash-keyed table decides
-};
-template <int LPP>
-__device__ __forceinline__ MkRes mk_probe_wave(const BkEntry* __restrict__ mk, uint32_t nbm, bool want, uint64_t code, uint64_t rc) {
-    const uint32_t home = want ? mk_home(minimizer23(code, rc), nbm) : AIX_BK_NONE;
-    MkRes out{0u, 0u, 0u, 0u};
-    bool open = want;                        // still walking the chain
-    uint32_t ovf_home = 0;
-#pragma unroll 1
-    for (int step = 0; step < AIX_MK_CHAIN; ++step) {
-        if (__ballot(open) == 0ull) break;
-        const BkRes k = line_probe_wave<LPP, true>(mk, open ? home + (uint32_t)step : AIX_BK_NONE, code);
-        if (open) {
-            if (step == 0) ovf_home = k.overflow;
-            if (k.found) { out.found = 1u; out.tf = k.tf; out.slot = k.slot; open = false; }
-            else if (!k.full) { out.undecided = ovf_home; open = false; }          // a free entry ends the chain: absent, unless keys of this home were left out
-        }
-    }
-    if (open) out.undecided = 1u;            // the whole chain was full
-    return out;
 }
 
 }  // namespace aix

@@ -24,7 +24,7 @@ struct IndexDev {
     uint32_t bk_lpp;          // lanes that share one bucket read (8, 4, 2 or 1); launch-time choice
     const uint64_t* bloom;    // 23-mer: absence filter in front of the table (nbloom 64-bit words), nullptr when off
     uint32_t nbloom;
-    const BkEntry* mk;        // 23-mer: minimizer-keyed copy of the table for streaming probes (nbm + AIX_MK_CHAIN lines), nullptr when off
+    const BkEntry* mk;        // 23-mer: minimizer-keyed copy of the table for the streaming counter (nbm buckets of AIX_MK_ENTRIES), nullptr when off
     uint32_t nbm;
 };
 
@@ -57,7 +57,7 @@ hipError_t launch_set_fingerprints(const MphfDev& m, BvRec* recs_rw, EeRec* ee_r
 // verification table: bk (nb * 8 entries) is initialised and filled from the keys that sit in their own MPHF slot;
 // fill = nb zeroed u32 counters (scratch)
 hipError_t launch_build_buckets(const MphfDev& m, const KeyRec* keys, uint64_t n, BkEntry* bk, uint32_t nb, uint32_t* fill, uint64_t* bloom /* zeroed, nullable */,
-                                uint32_t nbloom, BkEntry* mk /* nullable */, uint32_t nbm, uint32_t* mfill /* nbm + AIX_MK_CHAIN zeroed words */,
+                                uint32_t nbloom, BkEntry* mk /* nullable */, uint32_t nbm, uint32_t* mfill /* nbm zeroed words */,
                                 uint32_t* unfiled /* zeroed counter */, hipStream_t s);
 hipError_t launch_scatter23(const MphfDev& m, uint64_t n, uint64_t nslots, const uint8_t* keys_ascii /* or */, const uint64_t* codes, const uint32_t* counts,
                             uint64_t* checker, uint32_t* tf, uint32_t* occupied_bits, uint32_t* conflict, hipStream_t s);
@@ -75,7 +75,8 @@ hipError_t launch_count13_partitioned(const uint8_t* buf, uint64_t len, void* wo
 hipError_t launch_histogram_slots(const uint32_t* d_slots, uint64_t nslots, void* workspace /* count13_workspace_bytes(nslots + 12) */, uint32_t* tf_out,
                                   uint64_t n, hipStream_t s);
 // the same slot stream from the minimizer-keyed table (aix_stream23.hip): a lane owns 32 consecutive windows; needs ix.mk
-hipError_t launch_stream23_slots(const IndexDev& ix, const uint8_t* buf, uint64_t len, int canon_mode, uint32_t* slots /* [len - 22] */, hipStream_t s);
+hipError_t launch_stream23_slots(const IndexDev& ix, const uint8_t* buf, uint64_t len, int canon_mode, uint32_t* slots /* [len - 22] */,
+                                 uint32_t* flag /* zeroed word: set when a window stayed undecided */, hipStream_t s);
 hipError_t launch_probe23_slots(const IndexDev& ix, const uint8_t* buf, uint64_t len, int canon_mode, uint32_t* slots /* [len - 22] */, hipStream_t s);
 hipError_t launch_scatter13_to_mphf(const uint32_t* perm, const unsigned long long* table_code, uint64_t* out_mphf, int add, hipStream_t s);
 hipError_t launch_perm13_check(const uint32_t* perm, uint32_t* bits /* 4^13 / 32 zeroed words */, uint32_t* bad /* zeroed */, hipStream_t s);

@@ -23,7 +23,7 @@ static inline unsigned grid_for(uint64_t work, unsigned per_block = kBlock) {
 struct Probe {
     uint64_t slot;
     uint32_t tf;
-    uint32_t lines;     // instrumentation for MODE_LINES: MPHF records read | 16 per key record read | 256 per completed evaluation | 4096 per filter word | 65536 per bucket line | 2^20 per minimizer-table probe
+    uint32_t lines;     // instrumentation for MODE_LINES: MPHF records read | 16 per key record read | 256 per completed evaluation | 4096 per filter word | 65536 per bucket line
     bool found;
 };
 // MPHF path: evaluate the MPHF on the hash (a, b, c) of the probed bytes, verify against the stored code.
@@ -80,16 +80,7 @@ __device__ __forceinline__ Probe probe23_wave(const IndexDev& ix, bool want, uin
                                               bool absence = true) {
     Probe r;
     r.found = false; r.tf = 0; r.slot = 0; r.lines = 0;
-    bool rest = want;                                           // lanes the hash-keyed path still has to answer
-    if (ix.mk) {                                                // streaming kernels: the minimizer-keyed table first (no Jenkins hash at all)
-        const bool use = want && filters;
-        const MkRes k = mk_probe_wave<1>(ix.mk, ix.nbm, use, code, revcomp(code, 23));   // every lane its own line: neighbours want the same one, the loads coalesce
-        if (use) {
-            r.lines = 1048576;
-            if (k.found) { r.found = true; r.tf = k.tf; r.slot = k.slot; rest = false; }
-            else if (!k.undecided) rest = false;
-        }
-    }
+    const bool rest = want;
     uint64_t a = 0, b = 0, c = 0;
     if (rest) jenkins23(w0, w1, w2, ix.m.seed, a, b, c);
     bool mphf = rest;
@@ -229,8 +220,7 @@ __device__ __forceinline__ void both23(const IndexDev& ix, bool active, uint64_t
 
 template <int MODE, bool CANON, int LPP>
 __global__ void __launch_bounds__(kBlock) k_lookup23_ascii(const IndexDev ix_, const uint8_t* __restrict__ q, uint64_t N, LookupOut out) {
-    IndexDev ix = ix_;
-    ix.mk = nullptr;                          // a batch of unrelated queries has no minimizer locality: the hash-keyed table, one line per query
+    const IndexDev& ix = ix_;
     FilterGauge fg;
     AIX_WAVE_LOOP(i, N) {
         const bool in = i < N;
@@ -271,8 +261,7 @@ __global__ void __launch_bounds__(kBlock) k_lookup23_ascii(const IndexDev ix_, c
 
 template <bool CANON, int LPP>
 __global__ void __launch_bounds__(kBlock) k_lookup23_codes(const IndexDev ix_, const uint64_t* __restrict__ codes, uint64_t N, uint32_t* __restrict__ out) {
-    IndexDev ix = ix_;
-    ix.mk = nullptr;
+    const IndexDev& ix = ix_;
     FilterGauge fg;
     AIX_WAVE_LOOP(i, N) {
         const bool in = i < N;
@@ -416,8 +405,7 @@ __global__ void __launch_bounds__(kBlock) k_lookup13_ragged(const IndexDev ix, c
 template <bool CANON, int LPP>
 __global__ void __launch_bounds__(kBlock) k_coverage(const IndexDev ix_, const uint8_t* __restrict__ seqs, const uint64_t* __restrict__ offs, uint64_t M,
                                                     uint64_t total, uint32_t cutoff, uint32_t* __restrict__ out, const uint64_t* __restrict__ out_offs) {
-    IndexDev ix = ix_;
-    if (ix.mk) ix.bloom = nullptr;            // consecutive windows: the minimizer-keyed table answers present and absent windows from a shared line
+    const IndexDev& ix = ix_;
     const uint32_t k = ix.k;
     FilterGauge fg;
     AIX_WAVE_LOOP(p, total) {
@@ -551,21 +539,18 @@ __global__ void __launch_bounds__(kBlock) k_bk_fill(const MphfDev m, const KeyRe
         BkEntry e;
         e.code_lo = (uint32_t)kr.code; e.code_hi = (uint32_t)(kr.code >> 32); e.tf = kr.tf; e.slot = (uint32_t)i;
         if (pos < 8u) bk[(uint64_t)bi * 8 + pos] = e;
-        if (mk) {                                               // the same entry under its minimizer: home line, else the next ones
+        if (mk) {                                               // the same entry under its minimizer (16-entry buckets)
             const uint32_t home = mk_home(minimizer23(kr.code, revcomp(kr.code, 23)), nbm);
-            bool placed = false;
-            for (uint32_t j = 0; j < (uint32_t)AIX_MK_CHAIN && !placed; ++j) {
-                const uint32_t p2 = atomicAdd(&mfill[home + j], 1u) & 0x7FFFFFFFu;
-                if (p2 < 8u) { mk[(uint64_t)(home + j) * 8 + p2] = e; placed = true; }
-            }
-            if (!placed) { atomicOr(&mfill[home], 0x80000000u); atomicAdd(unfiled, 1u); }
+            const uint32_t p2 = atomicAdd(&mfill[home], 1u);
+            if (p2 < (uint32_t)AIX_MK_ENTRIES) mk[(uint64_t)home * AIX_MK_ENTRIES + p2] = e;
+            else atomicAdd(unfiled, 1u);
         }
     }
 }
-__global__ void __launch_bounds__(kBlock) k_mk_flag(BkEntry* __restrict__ mk, uint32_t nlines, const uint32_t* __restrict__ mfill) {
+__global__ void __launch_bounds__(kBlock) k_mk_flag(BkEntry* __restrict__ mk, uint32_t nbm, const uint32_t* __restrict__ mfill) {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t bi = (uint64_t)blockIdx.x * kBlock + threadIdx.x; bi < nlines; bi += stride)
-        if (mfill[bi] & 0x80000000u) mk[bi * 8 + 7].code_hi |= AIX_BK_OVERFLOW;      // a home line with keys left out is full: entry 7 exists
+    for (uint64_t bi = (uint64_t)blockIdx.x * kBlock + threadIdx.x; bi < nbm; bi += stride)
+        if (mfill[bi] > (uint32_t)AIX_MK_ENTRIES) mk[bi * AIX_MK_ENTRIES + AIX_MK_ENTRIES - 1].code_hi |= AIX_BK_OVERFLOW;   // keys were left out
 }
 __global__ void __launch_bounds__(kBlock) k_bk_flag(BkEntry* __restrict__ bk, uint32_t nb, const uint32_t* __restrict__ fill) {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
@@ -962,9 +947,9 @@ hipError_t launch_build_buckets(const MphfDev& m, const KeyRec* keys, uint64_t n
                                 uint32_t nbm, uint32_t* mfill, uint32_t* unfiled, hipStream_t s) {
     if (n == 0 || nb == 0) return hipSuccess;
     hipLaunchKernelGGL(k_bk_init, dim3(grid_for((uint64_t)nb * 8)), dim3(kBlock), 0, s, bk, (uint64_t)nb * 8);
-    if (mk) hipLaunchKernelGGL(k_bk_init, dim3(grid_for((uint64_t)(nbm + AIX_MK_CHAIN) * 8)), dim3(kBlock), 0, s, mk, (uint64_t)(nbm + AIX_MK_CHAIN) * 8);
+    if (mk) hipLaunchKernelGGL(k_bk_init, dim3(grid_for((uint64_t)nbm * AIX_MK_ENTRIES)), dim3(kBlock), 0, s, mk, (uint64_t)nbm * AIX_MK_ENTRIES);
     hipLaunchKernelGGL(k_bk_fill, dim3(grid_for(n)), dim3(kBlock), 0, s, m, keys, n, bk, nb, fill, bloom, nbloom, mk, nbm, mfill, unfiled);
-    if (mk) hipLaunchKernelGGL(k_mk_flag, dim3(grid_for(nbm + AIX_MK_CHAIN)), dim3(kBlock), 0, s, mk, nbm + AIX_MK_CHAIN, (const uint32_t*)mfill);
+    if (mk) hipLaunchKernelGGL(k_mk_flag, dim3(grid_for(nbm)), dim3(kBlock), 0, s, mk, nbm, (const uint32_t*)mfill);
     AIX_LAUNCH(k_bk_flag, nb, s, bk, nb, (const uint32_t*)fill);
 }
 hipError_t launch_scatter23(const MphfDev& m, uint64_t n, uint64_t nslots, const uint8_t* keys, const uint64_t* codes, const uint32_t* counts, uint64_t* checker, uint32_t* tf,

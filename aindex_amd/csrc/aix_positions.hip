@@ -60,14 +60,7 @@ __global__ void __launch_bounds__(kB) k_a2_probe(const IndexDev ix, const uint8_
         uint64_t x0 = w0, x1 = w1, x2 = w2;                                     // forward: the raw bytes of the window
         if (!fwd) ascii23_of_rc(e.code, x0, x1, x2);
         const bool tab = probe && (e.valid || !fwd);                            // the hashed bytes are the ASCII of `want`
-        bool rest = probe;                                                      // windows the hash-keyed path still has to answer
-        if (ix.mk) {                                                            // consecutive windows share their minimizer's line
-            const MkRes k = mk_probe_wave<1>(ix.mk, ix.nbm, tab, want, fwd ? r : e.code);
-            if (tab) {
-                if (k.found) { key = k.slot; rest = false; }
-                else if (!k.undecided) rest = false;
-            }
-        }
+        const bool rest = probe;
         uint64_t a = 0, b = 0, c = 0;
         if (rest) jenkins23(x0, x1, x2, ix.m.seed, a, b, c);
         bool mphf = rest;

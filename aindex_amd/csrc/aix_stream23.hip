@@ -10,10 +10,11 @@
 //     code is a funnel shift of that stream;
 //   * the minimizer (smallest hash among the nine canonical 15-mers of the window) is kept incrementally: one new 15-mer hash
 //     per window, minimum over a ring of nine;
-//   * about seven windows in a row share a minimizer, hence the home line of the table: the line stays in the lane's registers
-//     and is re-read only when the minimizer changes — one HBM line per super-k-mer, no hash of the k-mer at all.
-// A window the table cannot decide (chain of full lines, overflow bit) is written as UNDECIDED and settled afterwards by
-// k_fix23 through the MPHF path, so the result is exactly that of k_probe23_slots.
+//   * about seven windows in a row share a minimizer, hence their bucket of the table: the bucket (16 entries, two lines) stays
+//     in the lane's registers and is re-read only when the minimizer changes — one HBM read per super-k-mer, no hash of the
+//     k-mer at all.
+// A window the table cannot decide (its bucket carries the overflow bit and does not hold the code) is written as UNDECIDED
+// and settled afterwards by k_fix23 through the MPHF path, so the result is exactly that of k_probe23_slots.
 #include "aix_internal.hpp"
 
 namespace aix {
@@ -87,34 +88,29 @@ __device__ __forceinline__ uint32_t mmer_hash_at(const Run23& r) {
     return mmer_mix(f < g ? f : g);
 }
 
-struct LineRegs {
-    uint4 e[8];
+struct BucketRegs {
+    uint4 e[AIX_MK_ENTRIES];
 };
-__device__ __forceinline__ void load_line(const BkEntry* __restrict__ tab, uint32_t line, LineRegs& L) {
-    const uint4* p = (const uint4*)(tab + (uint64_t)line * 8);
+__device__ __forceinline__ void load_bucket(const BkEntry* __restrict__ tab, uint32_t b, BucketRegs& L) {
+    const uint4* p = (const uint4*)(tab + (uint64_t)b * AIX_MK_ENTRIES);
 #pragma unroll
-    for (int t = 0; t < 8; ++t) L.e[t] = p[t];
+    for (int t = 0; t < AIX_MK_ENTRIES; ++t) L.e[t] = p[t];      // two 128-byte lines, sixteen independent loads in flight
 }
-// compare `code` with the eight entries: returns the slot (or NONE), full / overflow of the line
-__device__ __forceinline__ uint32_t scan_line(const LineRegs& L, uint64_t code, bool& full, bool& ovf) {
+// compare `code` with the sixteen entries: the slot (or NONE); ovf = keys of this bucket were left out
+__device__ __forceinline__ uint32_t scan_bucket(const BucketRegs& L, uint64_t code, bool& ovf) {
     const uint32_t lo = (uint32_t)code, hi = (uint32_t)(code >> 32);
     uint32_t slot = S23_NONE;
-    bool hole = false;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const uint32_t y = L.e[t].y & AIX_BK_HI_MASK;
-        if (L.e[t].x == lo && y == hi) slot = L.e[t].w;
-        hole = hole || y == AIX_BK_EMPTY_HI;
-    }
-    full = !hole;
-    ovf = (L.e[7].y & AIX_BK_OVERFLOW) != 0;
+    for (int t = 0; t < AIX_MK_ENTRIES; ++t)
+        if (L.e[t].x == lo && (L.e[t].y & AIX_BK_HI_MASK) == hi) slot = L.e[t].w;
+    ovf = (L.e[AIX_MK_ENTRIES - 1].y & AIX_BK_OVERFLOW) != 0;
     return slot;
 }
 
 struct StreamState {
     uint32_t mh[9];       // ring: hashes of the nine canonical 15-mers of the current window (position p lives in mh[p % 9])
-    uint32_t cur;         // line held in `home_line`
-    LineRegs home_line;
+    uint32_t cur;         // bucket held in `regs`
+    BucketRegs regs;
 };
 
 template <int J>
@@ -139,36 +135,19 @@ __device__ __forceinline__ void stream_steps(const IndexDev& ix, const Run23& ru
             if (x < code) { key = x; mz = minimizer23(x, revcomp(x, 23)); }          // kmer_counter's pseudo-complement is no strand of the window: its own minimizer
         }
         const uint32_t home = mk_home(mz, ix.nbm);
-        bool open = want;
-        bool ovf_home = false;
-        if (want && home != st.cur) { load_line(ix.mk, home, st.home_line); st.cur = home; }
-        if (open) {
-            bool full, ovf;
-            const uint32_t s = scan_line(st.home_line, key, full, ovf);
-            if (s != S23_NONE) { slot = s; open = false; }
-            else if (!full) { slot = ovf ? S23_UND : S23_NONE; open = false; }
-            else ovf_home = ovf;
+        if (want && home != st.cur) { load_bucket(ix.mk, home, st.regs); st.cur = home; }   // ~ once per seven windows
+        if (want) {
+            bool ovf;
+            const uint32_t s = scan_bucket(st.regs, key, ovf);
+            slot = s != S23_NONE ? s : (ovf ? S23_UND : S23_NONE);
         }
-#pragma unroll 1
-        for (int step = 1; step < AIX_MK_CHAIN; ++step) {                            // the home line was full: the next lines, not cached
-            if (__ballot(open) == 0ull) break;
-            if (open) {
-                LineRegs nx;
-                load_line(ix.mk, home + (uint32_t)step, nx);
-                bool full, ovf;
-                const uint32_t s = scan_line(nx, key, full, ovf);
-                if (s != S23_NONE) { slot = s; open = false; }
-                else if (!full) { slot = ovf_home ? S23_UND : S23_NONE; open = false; }
-            }
-        }
-        if (open) slot = S23_UND;                                                    // the whole chain was full
         tr[J] = slot;
         stream_steps<J + 1>(ix, run, valid, canon_mode, st, tr);
     }
 }
 
 __global__ void __launch_bounds__(S23_TB) k_stream23_slots(const IndexDev ix, const uint8_t* __restrict__ buf, uint64_t len, uint64_t nwin, int canon_mode,
-                                                          uint32_t* __restrict__ slots) {
+                                                          uint32_t* __restrict__ slots, uint32_t* __restrict__ any_undecided) {
     __shared__ uint32_t tr[S23_TB / 64][64 * (S23_W + 1)];       // per wave: lane-major results, transposed into coalesced stores
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t wave_first = ((uint64_t)blockIdx.x * S23_TB + (threadIdx.x & ~63u)) * S23_W;     // first window start of this wave
@@ -181,7 +160,7 @@ __global__ void __launch_bounds__(S23_TB) k_stream23_slots(const IndexDev ix, co
     StreamState st;
     st.cur = AIX_BK_NONE;
 #pragma unroll
-    for (int t = 0; t < 8; ++t) st.home_line.e[t] = make_uint4(0xFFFFFFFFu, AIX_BK_EMPTY_HI, 0u, 0u);
+    for (int t = 0; t < AIX_MK_ENTRIES; ++t) st.regs.e[t] = make_uint4(0xFFFFFFFFu, AIX_BK_EMPTY_HI, 0u, 0u);
     st.mh[0] = mmer_hash_at<0>(run); st.mh[1] = mmer_hash_at<1>(run); st.mh[2] = mmer_hash_at<2>(run);
     st.mh[3] = mmer_hash_at<3>(run); st.mh[4] = mmer_hash_at<4>(run); st.mh[5] = mmer_hash_at<5>(run);
     st.mh[6] = mmer_hash_at<6>(run); st.mh[7] = mmer_hash_at<7>(run); st.mh[8] = mmer_hash_at<8>(run);
@@ -190,17 +169,21 @@ __global__ void __launch_bounds__(S23_TB) k_stream23_slots(const IndexDev ix, co
     // the wave's 2048 results leave as 32 coalesced 256-byte stores (only this wave touches its LDS region)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    bool und = false;
 #pragma unroll 4
     for (int i = 0; i < S23_W; ++i) {
         const uint32_t idx = (uint32_t)i * 64u + lane;                               // position inside the wave's span
         const uint32_t v = tr[wave][(idx >> 5) * (S23_W + 1) + (idx & 31u)];
         const uint64_t p = wave_first + idx;
-        if (p < nwin) slots[p] = v;
+        if (p < nwin) { slots[p] = v; und = und || v == S23_UND; }
     }
+    if (__ballot(und) != 0ull && lane == 0) *any_undecided = 1u;                      // k_fix23 has something to do
 }
 
 // windows the table left UNDECIDED: the MPHF path, lane by lane (rare)
-__global__ void __launch_bounds__(256) k_fix23(const IndexDev ix_, const uint8_t* __restrict__ buf, uint64_t nwin, int canon_mode, uint32_t* __restrict__ slots) {
+__global__ void __launch_bounds__(256) k_fix23(const IndexDev ix_, const uint8_t* __restrict__ buf, uint64_t nwin, int canon_mode, uint32_t* __restrict__ slots,
+                                              const uint32_t* __restrict__ any_undecided) {
+    if (*any_undecided == 0u) return;                                                // the usual case: nothing was left undecided
     IndexDev ix = ix_;
     ix.early_exit = 0;
     const uint64_t stride = (uint64_t)gridDim.x * 256;
@@ -229,16 +212,16 @@ __global__ void __launch_bounds__(256) k_fix23(const IndexDev ix_, const uint8_t
     }
 }
 
-// slots[0, len - 22) for a PLAIN buffer; needs ix.mk
-hipError_t launch_stream23_slots(const IndexDev& ix, const uint8_t* buf, uint64_t len, int canon_mode, uint32_t* slots, hipStream_t s) {
+// slots[0, len - 22) for a PLAIN buffer; needs ix.mk. flag: one zeroed device word (set when a window was left undecided)
+hipError_t launch_stream23_slots(const IndexDev& ix, const uint8_t* buf, uint64_t len, int canon_mode, uint32_t* slots, uint32_t* flag, hipStream_t s) {
     if (len < 23 || ix.n == 0 || !ix.mk) return hipSuccess;
     const uint64_t nwin = len - 22;
     const uint64_t per_block = (uint64_t)S23_TB * S23_W;
     const uint64_t blocks = (nwin + per_block - 1) / per_block;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_stream23_slots, dim3((unsigned)blocks), dim3(S23_TB), 0, s, ix, buf, len, nwin, canon_mode, slots);
+    hipLaunchKernelGGL(k_stream23_slots, dim3((unsigned)blocks), dim3(S23_TB), 0, s, ix, buf, len, nwin, canon_mode, slots, flag);
     const uint64_t fb = (nwin + 255) / 256;
-    hipLaunchKernelGGL(k_fix23, dim3((unsigned)(fb > 16384 ? 16384 : fb)), dim3(256), 0, s, ix, buf, nwin, canon_mode, slots);
+    hipLaunchKernelGGL(k_fix23, dim3((unsigned)(fb > 16384 ? 16384 : fb)), dim3(256), 0, s, ix, buf, nwin, canon_mode, slots, (const uint32_t*)flag);
     return hipGetLastError();
 }
 

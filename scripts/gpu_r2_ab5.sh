@@ -19,8 +19,8 @@ AIX_MINIMIZER_TABLE=1 run cov_mk --workload coverage23 --seqs 100000 $B || exit 
 run cov_nomk --workload coverage23 --seqs 100000 --no-minimizer-table $B || exit 5
 AIX_MINIMIZER_TABLE=1 run pos_mk --workload positions23 --reads 5000000 $B || exit 5
 run pos_nomk --workload positions23 --reads 5000000 --no-minimizer-table $B || exit 5
-AIX_MINIMIZER_TABLE=1 AIX_MINIMIZER_LOAD=2 run count23_mk_load2 --workload count23 --reads 10000000 $B || exit 5
-AIX_MINIMIZER_TABLE=1 AIX_MINIMIZER_LOAD=4 run count23_mk_load4 --workload count23 --reads 10000000 $B || exit 5
+AIX_MINIMIZER_TABLE=1 AIX_MINIMIZER_LOAD=4 run count23_mk_load4b --workload count23 --reads 10000000 $B || exit 5
+AIX_MINIMIZER_TABLE=1 AIX_MINIMIZER_LOAD=8 run count23_mk_load8 --workload count23 --reads 10000000 $B || exit 5
 grep -h "index:" $O/count23_mk.err | tail -1
 export TMPDIR=/tmp; cd /tmp
 step "rocprofv3 kernel trace: count23"

