@@ -490,14 +490,10 @@ __device__ __forceinline__ BkRes bucket_probe_wave(const BkEntry* __restrict__ b
 // the smallest hash, taken over both strands, so it is the same for a k-mer and its reverse complement). Filing a key under
 // its minimizer instead of its own hash sends those windows to the SAME bucket: one HBM read per super-k-mer instead of one
 // per window. A bucket is 16 entries = two 128-byte lines read together (the keys of one minimizer arrive in groups, so the
-// buckets fill unevenly); a key that finds its home bucket full goes to a second-choice bucket (another hash of the
-// minimizer) and the home bucket's last entry gets the DISPLACED bit; a key that finds both full stays out (DROPPED bit). A
-// probe reads its home bucket; only if the code is not there and the bucket is marked does it read the second one; only if
-// keys were dropped is it UNDECIDED and settled by the MPHF path.
+// buckets fill unevenly); a key that finds its bucket full stays out and the bucket's last entry gets the overflow bit: a
+// probe that does not find its code in such a bucket is UNDECIDED and is settled by the MPHF path.
 // ---------------------------------------------------------------------------------------------
 #define AIX_MK_ENTRIES 16
-#define AIX_MK_DISPLACED 0x80000000u      /* last entry of a bucket: keys homed here live in their second-choice bucket  */
-#define AIX_MK_DROPPED   0x40000000u      /* last entry of a bucket: keys homed here found both buckets full (MPHF path) */
 __device__ __forceinline__ uint32_t mmer_mix(uint32_t x) {        // a bijection of u32: equal hashes <=> equal 15-mers
     x *= 0x9E3779B1u; x ^= x >> 15; x *= 0x85EBCA77u; x ^= x >> 13;
     return x;
@@ -525,11 +521,6 @@ __device__ __forceinline__ uint32_t minimizer23(uint64_t u, uint64_t r) {
 __device__ __forceinline__ uint32_t mk_home(uint32_t minimizer, uint32_t nbm) {      // the minimum of nine hashes is skewed towards 0: mixed again
     uint64_t z = ((uint64_t)minimizer + 1ull) * 0x9E3779B97F4A7C15ULL;
     z ^= z >> 29; z *= 0xBF58476D1CE4E5B9ULL; z ^= z >> 32;
-    return (uint32_t)__umul64hi(z, (uint64_t)nbm);
-}
-__device__ __forceinline__ uint32_t mk_alt(uint32_t minimizer, uint32_t nbm) {       // second choice
-    uint64_t z = ((uint64_t)minimizer ^ 0x5851F42Dull) * 0xD6E8FEB86659FD93ULL;
-    z ^= z >> 32; z *= 0xD6E8FEB86659FD93ULL; z ^= z >> 32;
     return (uint32_t)__umul64hi(z, (uint64_t)nbm);
 }
 

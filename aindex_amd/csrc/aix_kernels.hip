@@ -540,23 +540,17 @@ __global__ void __launch_bounds__(kBlock) k_bk_fill(const MphfDev m, const KeyRe
         e.code_lo = (uint32_t)kr.code; e.code_hi = (uint32_t)(kr.code >> 32); e.tf = kr.tf; e.slot = (uint32_t)i;
         if (pos < 8u) bk[(uint64_t)bi * 8 + pos] = e;
         if (mk) {                                               // the same entry under its minimizer (16-entry buckets)
-            const uint32_t mz = minimizer23(kr.code, revcomp(kr.code, 23));
-            const uint32_t home = mk_home(mz, nbm);
-            const uint32_t p2 = atomicAdd(&mfill[home], 1u) & 0x00FFFFFFu;
+            const uint32_t home = mk_home(minimizer23(kr.code, revcomp(kr.code, 23)), nbm);
+            const uint32_t p2 = atomicAdd(&mfill[home], 1u);
             if (p2 < (uint32_t)AIX_MK_ENTRIES) mk[(uint64_t)home * AIX_MK_ENTRIES + p2] = e;
-            else {                                              // home is full: the second-choice bucket
-                const uint32_t alt = mk_alt(mz, nbm);
-                const uint32_t p3 = atomicAdd(&mfill[alt], 1u) & 0x00FFFFFFu;
-                if (p3 < (uint32_t)AIX_MK_ENTRIES) { mk[(uint64_t)alt * AIX_MK_ENTRIES + p3] = e; atomicOr(&mfill[home], AIX_MK_DISPLACED); }
-                else { atomicOr(&mfill[home], AIX_MK_DISPLACED | AIX_MK_DROPPED); atomicAdd(unfiled, 1u); }
-            }
+            else atomicAdd(unfiled, 1u);
         }
     }
 }
 __global__ void __launch_bounds__(kBlock) k_mk_flag(BkEntry* __restrict__ mk, uint32_t nbm, const uint32_t* __restrict__ mfill) {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t bi = (uint64_t)blockIdx.x * kBlock + threadIdx.x; bi < nbm; bi += stride)
-        mk[bi * AIX_MK_ENTRIES + AIX_MK_ENTRIES - 1].code_hi |= mfill[bi] & (AIX_MK_DISPLACED | AIX_MK_DROPPED);   // only a full bucket displaces: its last entry is a key
+        if (mfill[bi] > (uint32_t)AIX_MK_ENTRIES) mk[bi * AIX_MK_ENTRIES + AIX_MK_ENTRIES - 1].code_hi |= AIX_BK_OVERFLOW;   // keys were left out
 }
 __global__ void __launch_bounds__(kBlock) k_bk_flag(BkEntry* __restrict__ bk, uint32_t nb, const uint32_t* __restrict__ fill) {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;

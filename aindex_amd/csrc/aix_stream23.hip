@@ -96,14 +96,14 @@ __device__ __forceinline__ void load_bucket(const BkEntry* __restrict__ tab, uin
 #pragma unroll
     for (int t = 0; t < AIX_MK_ENTRIES; ++t) L.e[t] = p[t];      // two 128-byte lines, sixteen independent loads in flight
 }
-// compare `code` with the sixteen entries: the slot (or NONE); marks = DISPLACED / DROPPED bits of the bucket
-__device__ __forceinline__ uint32_t scan_bucket(const BucketRegs& L, uint64_t code, uint32_t& marks) {
+// compare `code` with the sixteen entries: the slot (or NONE); ovf = keys of this bucket were left out
+__device__ __forceinline__ uint32_t scan_bucket(const BucketRegs& L, uint64_t code, bool& ovf) {
     const uint32_t lo = (uint32_t)code, hi = (uint32_t)(code >> 32);
     uint32_t slot = S23_NONE;
 #pragma unroll
     for (int t = 0; t < AIX_MK_ENTRIES; ++t)
         if (L.e[t].x == lo && (L.e[t].y & AIX_BK_HI_MASK) == hi) slot = L.e[t].w;
-    marks = L.e[AIX_MK_ENTRIES - 1].y & (AIX_MK_DISPLACED | AIX_MK_DROPPED);
+    ovf = (L.e[AIX_MK_ENTRIES - 1].y & AIX_BK_OVERFLOW) != 0;
     return slot;
 }
 
@@ -137,16 +137,9 @@ __device__ __forceinline__ void stream_steps(const IndexDev& ix, const Run23& ru
         const uint32_t home = mk_home(mz, ix.nbm);
         if (want && home != st.cur) { load_bucket(ix.mk, home, st.regs); st.cur = home; }   // ~ once per seven windows
         if (want) {
-            uint32_t marks;
-            slot = scan_bucket(st.regs, key, marks);
-            if (slot == S23_NONE && (marks & AIX_MK_DISPLACED)) {                    // keys of this home were moved: the second-choice bucket (rare)
-                const uint32_t alt = mk_alt(mz, ix.nbm);
-                load_bucket(ix.mk, alt, st.regs);
-                st.cur = alt;
-                uint32_t m2;
-                slot = scan_bucket(st.regs, key, m2);
-                if (slot == S23_NONE && (marks & AIX_MK_DROPPED)) slot = S23_UND;     // some were dropped: the MPHF path decides
-            }
+            bool ovf;
+            const uint32_t s = scan_bucket(st.regs, key, ovf);
+            slot = s != S23_NONE ? s : (ovf ? S23_UND : S23_NONE);
         }
         tr[J] = slot;
         stream_steps<J + 1>(ix, run, valid, canon_mode, st, tr);
