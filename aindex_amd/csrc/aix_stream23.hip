@@ -186,9 +186,16 @@ __global__ void __launch_bounds__(256) k_fix23(const IndexDev ix_, const uint8_t
     if (*any_undecided == 0u) return;                                                // the usual case: nothing was left undecided
     IndexDev ix = ix_;
     ix.early_exit = 0;
-    const uint64_t stride = (uint64_t)gridDim.x * 256;
-    for (uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x; p < nwin; p += stride) {
-        if (slots[p] != S23_UND) continue;
+    // the scan: four slots per lane and load (the slot array of a piece is 16-byte aligned), then the few undecided ones one by one
+    const uint64_t stride = (uint64_t)gridDim.x * 256 * 4;
+    for (uint64_t q = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4; q < nwin; q += stride) {
+        uint32_t v[4] = {0, 0, 0, 0};
+        if (q + 4 <= nwin) { const uint4 x = *(const uint4*)(slots + q); v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; }
+        else { for (int i = 0; i < 4; ++i) if (q + i < nwin) v[i] = slots[q + i]; }
+        if (v[0] != S23_UND && v[1] != S23_UND && v[2] != S23_UND && v[3] != S23_UND) continue;
+      for (int i = 0; i < 4; ++i) {
+        if (v[i] != S23_UND) continue;
+        const uint64_t p = q + i;
         uint64_t w0, w1, w2;
         load23(buf + p, w0, w1, w2);
         const uint64_t U = 0xDFDFDFDFDFDFDFDFULL;
@@ -209,6 +216,7 @@ __global__ void __launch_bounds__(256) k_fix23(const IndexDev ix_, const uint8_t
         const uint64_t h = mphf_from_hash(ix.m, a, b, c);
         if (h < ix.n && ix.keys[h].code == key) slot = (uint32_t)h;
         slots[p] = slot;
+      }
     }
 }
 
@@ -220,7 +228,7 @@ hipError_t launch_stream23_slots(const IndexDev& ix, const uint8_t* buf, uint64_
     const uint64_t blocks = (nwin + per_block - 1) / per_block;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_stream23_slots, dim3((unsigned)blocks), dim3(S23_TB), 0, s, ix, buf, len, nwin, canon_mode, slots, flag);
-    const uint64_t fb = (nwin + 255) / 256;
+    const uint64_t fb = (nwin + 1023) / 1024;
     hipLaunchKernelGGL(k_fix23, dim3((unsigned)(fb > 16384 ? 16384 : fb)), dim3(256), 0, s, ix, buf, nwin, canon_mode, slots, (const uint32_t*)flag);
     return hipGetLastError();
 }
