@@ -87,9 +87,89 @@ __device__ __forceinline__ uint32_t block_scan_excl(uint32_t mine, uint32_t* wsu
 }
 
 // ---------------------------------------------------------------------------------------------
+// level 1 sources: sixteen codes per lane and tile
+// ---------------------------------------------------------------------------------------------
+struct K1Codes {                                      // an array of window codes (~0 = no k-mer), e.g. written by k_window_codes
+    const uint64_t* codes;
+    uint64_t n;
+    __device__ __forceinline__ void load(uint64_t tile, int t, uint64_t (&c)[K1_WPT]) const {
+        const uint64_t base = tile * K1_TILE + (uint64_t)t;   // code j of this lane = base + j * 1024: coalesced 8 KiB per load instruction
+#pragma unroll
+        for (int j = 0; j < K1_WPT; ++j) {
+            const uint64_t i = base + (uint64_t)j * K1_TB;
+            c[j] = i < n ? codes[i] : K1_INVALID;
+        }
+    }
+};
+// The windows of a PLAIN buffer, encoded here (count_kmers.cpp:93-136,297-308: A/C/G/T/U either case, canonical form by
+// canon_mode): a lane owns 16 consecutive window starts, its 16 + k - 1 bytes are turned ONCE into a 2-bit stream (4 bytes per
+// step) and every window is a shift of it — no 8-byte code per window is written to and read back from HBM.
+struct K1Plain {
+    const uint8_t* buf;
+    uint64_t len;         // bytes
+    uint64_t n;           // windows = len - k + 1
+    int k, canon_mode;
+    __device__ __forceinline__ void load(uint64_t tile, int t, uint64_t (&c)[K1_WPT]) const {
+        constexpr int ND = 10;                                // 40 bytes >= 16 + 23 - 1
+        const uint64_t S = tile * K1_TILE + (uint64_t)t * K1_WPT;
+#pragma unroll
+        for (int j = 0; j < K1_WPT; ++j) c[j] = K1_INVALID;
+        if (S >= n) return;
+        uint32_t e[ND];
+        {
+            const uint32_t o = (uint32_t)((uintptr_t)(buf + S) & 3);
+            const uint32_t* q = (const uint32_t*)(buf + S - o);
+            const int64_t first = (int64_t)S - o, end = (int64_t)len;
+            uint32_t d[ND + 1];
+#pragma unroll
+            for (int i = 0; i <= ND; ++i) d[i] = (first + 4 * i < end) ? q[i] : 0x0A0A0A0Au;   // never read a dword past the buffer
+            const uint32_t sh = o * 8;
+#pragma unroll
+            for (int i = 0; i < ND; ++i) e[i] = __funnelshift_r(d[i], d[i + 1], sh);
+        }
+        uint32_t w[3] = {0, 0, 0};
+        uint64_t vmask = 0;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            uint32_t x = e[i] & 0xDFDFDFDFu;
+            {   // 'U' -> 'T' (count_kmers.cpp:71-88)
+                const uint32_t z = x ^ 0x55555555u;
+                const uint32_t nz = (((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z) & 0x80808080u;
+                x ^= (~nz & 0x80808080u) >> 7;
+            }
+            const uint32_t v = ((x >> 1) ^ (x >> 2)) & 0x03030303u;
+            const uint32_t diff = x ^ lut4(v, AIX_LUT_ACGT);
+            const uint32_t z = ~(((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff | 0x7F7F7F7Fu);    // 0x80 in every byte where diff == 0
+            const uint32_t f = z >> 7;
+            const uint32_t nib = (f | (f >> 7) | (f >> 14) | (f >> 21)) & 0xFu;
+            const uint32_t q2 = ((v << 6) & 0xC0u) | ((v >> 4) & 0x30u) | ((v >> 14) & 0x0Cu) | (v >> 24);
+            w[i >> 2] |= q2 << (24 - 8 * (i & 3));
+            vmask |= (uint64_t)nib << (4 * i);
+        }
+        const uint64_t avail = len - S;                        // bytes from S to the end of the buffer
+        if (avail < 40) vmask &= (1ull << avail) - 1;
+        // window j holds a k-mer iff k consecutive mask bits are set
+        uint64_t run = vmask;
+        for (int i = 1; i < k; ++i) run &= vmask >> i;
+        const uint64_t hi = ((uint64_t)w[0] << 32) | w[1], lo = (uint64_t)w[2] << 32;
+        const uint64_t kmask = (1ULL << (2 * k)) - 1;
+#pragma unroll
+        for (int j = 0; j < K1_WPT; ++j) {
+            if (!((run >> j) & 1ull) || S + j >= n) continue;
+            const int sh = 128 - 2 * j - 2 * k;                // >= 52
+            uint64_t code = (sh >= 64 ? (hi >> (sh - 64)) : ((hi << (64 - sh)) | (lo >> sh))) & kmask;
+            if (canon_mode == 1) { const uint64_t x = revcomp_refx86(code, k); code = code < x ? code : x; }
+            else if (canon_mode == 2) { const uint64_t x = revcomp(code, k); code = code < x ? code : x; }
+            c[j] = code;
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
 // level 1
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(K1_TB) k_k1_split(const uint64_t* __restrict__ codes, uint64_t n, uint32_t s1, uint64_t ntiles, uint32_t region,
+template <class SRC>
+__global__ void __launch_bounds__(K1_TB) k_k1_split(const SRC src, uint32_t s1, uint64_t ntiles, uint32_t region,
                                                    uint16_t* __restrict__ dir_part, uint16_t* __restrict__ dir_cnt, uint64_t* __restrict__ parts,
                                                    uint32_t* __restrict__ err) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -107,13 +187,8 @@ __global__ void __launch_bounds__(K1_TB) k_k1_split(const uint64_t* __restrict__
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         uint64_t c[K1_WPT];
         uint32_t rank[K1_WPT / 2];
-        const uint64_t base = tile * K1_TILE + (uint64_t)t;     // code j of this lane = base + j * 1024: coalesced 8 KiB per load instruction
         const uint32_t dummy = K1_P + (t & (K1_DUMMY - 1));
-#pragma unroll
-        for (int j = 0; j < K1_WPT; ++j) {
-            const uint64_t i = base + (uint64_t)j * K1_TB;
-            c[j] = i < n ? codes[i] : K1_INVALID;
-        }
+        src.load(tile, t, c);
 #pragma unroll
         for (int j = 0; j < K1_WPT; ++j) {
             const bool ok = c[j] != K1_INVALID;
@@ -421,8 +496,10 @@ bool k1_msd_eligible(uint64_t nwin, int k) {
 // d_codes: nwin window codes (~0 = no k-mer), clobbered (re-used as staging). Outputs are pool blocks (caller releases).
 // *fell_back = true: a bucket overflowed, nothing was produced (the caller runs the radix-sort path on d_codes — intact in that case
 // only if it re-creates the codes, so the caller keeps a way to regenerate them).
+// d_plain != nullptr: the windows are encoded inside level 1 (no code array is read; d_codes is then only the 8 B-per-window
+// scratch the later stages re-use). plen = bytes of the PLAIN buffer.
 hipError_t distinct_from_codes_msd(uint64_t* d_codes, uint64_t nwin, int k, uint64_t** d_keys_out, uint32_t** d_counts_out, uint64_t* n_out, bool* fell_back,
-                                   hipStream_t s) {
+                                   hipStream_t s, const uint8_t* d_plain, uint64_t plen, int canon_mode) {
     *d_keys_out = nullptr; *d_counts_out = nullptr; *n_out = 0; *fell_back = false;
     const uint32_t B = 2u * (uint32_t)k, s1 = B - K1_PBITS;
     // D2: ~768 codes per bucket on average; the remainder must fit 32 bits
@@ -474,7 +551,8 @@ hipError_t distinct_from_codes_msd(uint64_t* d_codes, uint64_t nwin, int k, uint
     uint32_t flags[2] = {0, 0};
     uint32_t total_distinct = 0;
     do {
-        e = hipFuncSetAttribute((const void*)k_k1_split, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K1_TILE_LDS);
+        e = hipFuncSetAttribute((const void*)k_k1_split<K1Codes>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K1_TILE_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_k1_split<K1Plain>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K1_TILE_LDS);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k_k1_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)K1_TILE_LDS);
         if (e == hipSuccess) e = hipMemsetAsync(w, 0, 256, s);
         if (e == hipSuccess) e = hipMemsetD16Async((hipDeviceptr_t)dir_part, (unsigned short)K1_P, cap, s);      // "no partition": sorts behind every real one
@@ -482,7 +560,10 @@ hipError_t distinct_from_codes_msd(uint64_t* d_codes, uint64_t nwin, int k, uint
         if (e == hipSuccess) e = hipMemsetAsync(bucket_cnt, 0, 4ull * (nbuckets + 1), s);
         if (e == hipSuccess) e = hipMemsetAsync(distinct_m, 0, 4ull * (nbuckets + 1), s);
         if (e != hipSuccess) break;
-        hipLaunchKernelGGL(k_k1_split, dim3(grid), dim3(K1_TB), K1_TILE_LDS, s, (const uint64_t*)d_codes, nwin, s1, ntiles, region, dir_part, dir_cnt, parts, err);
+        if (d_plain) hipLaunchKernelGGL(k_k1_split<K1Plain>, dim3(grid), dim3(K1_TB), K1_TILE_LDS, s, K1Plain{d_plain, plen, nwin, k, canon_mode}, s1, ntiles, region,
+                                        dir_part, dir_cnt, parts, err);
+        else hipLaunchKernelGGL(k_k1_split<K1Codes>, dim3(grid), dim3(K1_TB), K1_TILE_LDS, s, K1Codes{(const uint64_t*)d_codes, nwin}, s1, ntiles, region, dir_part,
+                                dir_cnt, parts, err);
         auto vals = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), K1Desc{dir_cnt});
         size_t tb = sort_tmp;
         e = rocprim::radix_sort_pairs(tmp, tb, (const uint16_t*)dir_part, spart, vals, sdesc, (size_t)cap, 0u, 12u, s);

@@ -358,12 +358,12 @@ hipError_t distinct_from_plain(const uint8_t* d_plain, uint64_t plen, int k, int
         const uint64_t nwin = std::min(piece, nwin_all - w0);
         DevArr codes(s);
         e = codes.alloc(8 * nwin);
-        if (e == hipSuccess) e = launch_window_codes(d_plain + w0, nwin + k - 1, k, canon_mode, (uint64_t*)codes.p, s);
         uint64_t* pk = nullptr; uint32_t* pc = nullptr; uint64_t pm = 0;
         bool sorted_path = !k1_msd_eligible(nwin, k);
-        if (e == hipSuccess && !sorted_path) {                                // MSD partition + per-bucket LDS hash / sort (aix_k1.hip)
+        if (e == hipSuccess && sorted_path) e = launch_window_codes(d_plain + w0, nwin + k - 1, k, canon_mode, (uint64_t*)codes.p, s);
+        if (e == hipSuccess && !sorted_path) {                                // MSD partition + per-bucket LDS hash / sort (aix_k1.hip); windows encoded inside level 1
             bool fell_back = false;
-            e = distinct_from_codes_msd((uint64_t*)codes.p, nwin, k, &pk, &pc, &pm, &fell_back, s);
+            e = distinct_from_codes_msd((uint64_t*)codes.p, nwin, k, &pk, &pc, &pm, &fell_back, s, d_plain + w0, nwin + k - 1, canon_mode);
             if (e == hipSuccess && fell_back) {                               // a bucket too rich for LDS: the codes were used as staging, make them again
                 sorted_path = true;
                 e = launch_window_codes(d_plain + w0, nwin + k - 1, k, canon_mode, (uint64_t*)codes.p, s);
