@@ -89,7 +89,7 @@ __device__ __forceinline__ Probe probe23_wave(const IndexDev& ix, bool want, uin
             r.lines += 4096;
             const uint64_t z2 = code_mix2(z);
             const uint64_t m = bloom_mask(z2);
-            if ((ix.bloom[bloom_word(z2, ix.nbloom)] & m) != m) { use = false; mphf = false; }
+            if ((ix.bloom[bloom_word(z2 >> 24 | z2 << 40, ix.nbloom)] & m) != m) { use = false; mphf = false; }
         }
         const BkRes k = bucket_probe_wave<LPP>(ix.bk, ix.nb, use, z, code);
         if (use) {
@@ -526,7 +526,7 @@ __global__ void __launch_bounds__(kBlock) k_bk_fill(const MphfDev m, const KeyRe
         jenkins23(w0, w1, w2, m.seed, a, b, c);
         if (mphf_from_hash(m, a, b, c) != i) continue;         // not where the MPHF puts it: the reference cannot find it, neither can a probe
         const uint64_t z = code_mix(kr.code);
-        if (bloom) { const uint64_t z2 = code_mix2(z); atomicOr((unsigned long long*)&bloom[bloom_word(z2, nbloom)], (unsigned long long)bloom_mask(z2)); }
+        if (bloom) { const uint64_t z2 = code_mix2(z); atomicOr((unsigned long long*)&bloom[bloom_word(z2 >> 24 | z2 << 40, nbloom)], (unsigned long long)bloom_mask(z2)); }
         const uint32_t bi = bucket_of(z, nb);
         const uint32_t pos = atomicAdd(&fill[bi], 1u);
         BkEntry e;

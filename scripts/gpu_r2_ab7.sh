@@ -4,7 +4,6 @@ set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r2ab7; mkdir -p $O; cd $R
 step () { echo "== $1 $(date +%T)" | tee -a $O/progress.txt; }
 if [ "${SKIP_TESTS:-0}" != "1" ]; then
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "early_exit or bucket" 2>&1 | tail -2
 step "pytest gpu"
 timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; rc=$?; tail -4 $O/pytest_gpu.log
 [ $rc -eq 0 ] || { grep -n "^E " $O/pytest_gpu.log | head -20; exit 3; }
