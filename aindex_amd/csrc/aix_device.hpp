@@ -69,17 +69,6 @@ struct __attribute__((aligned(16))) BkEntry {
 // Bloom filter, one 64-bit word per probe, four bits per key, filled from the same keys as the table. It is small enough to
 // live in the Infinity Cache (16 bits per key by default), so an absent key is usually answered by ONE 8-byte cached read and
 // never reaches HBM; a filed key passes it by construction. Word and bits come from hash words the bucket choice does not use.
-// The verification table and its absence filter are OUR structures: they are keyed by a cheap mix of the 46-bit code itself
-// (two 64-bit multiplies), not by the Jenkins hash of the k-mer's ASCII — a probe the table answers needs neither the ASCII
-// decode nor the 12-round Jenkins mix (~150 VALU operations per probe); those are computed only on the MPHF path.
-__device__ __forceinline__ uint64_t code_mix(uint64_t code) {
-    uint64_t z = (code + 0x9E3779B97F4A7C15ULL) * 0xBF58476D1CE4E5B9ULL;
-    z ^= z >> 31;
-    z *= 0x94D049BB133111EBULL;
-    z ^= z >> 29;
-    return z;
-}
-__device__ __forceinline__ uint64_t code_mix2(uint64_t z) { return (z ^ (z >> 23)) * 0xD6E8FEB86659FD93ULL; }   // second stream of bits for the filter
 __device__ __forceinline__ uint64_t bloom_mask(uint64_t c) {
     return (1ull << (c & 63)) | (1ull << ((c >> 6) & 63)) | (1ull << ((c >> 12) & 63)) | (1ull << ((c >> 18) & 63));
 }

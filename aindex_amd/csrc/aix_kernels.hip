@@ -76,32 +76,29 @@ __device__ __forceinline__ Probe probe23_hashed(const IndexDev& ix, uint64_t a, 
 // others — and an unmatched probe of an overflowed bucket — by the MPHF path.
 // `absence`: consult the absence filter first (wave-uniform; the callers switch it per loop trip, see FilterGauge).
 template <int LPP>
-__device__ __forceinline__ Probe probe23_wave(const IndexDev& ix, bool want, uint64_t code, bool filters, bool absence, uint64_t raw0, uint64_t raw1, uint64_t raw2) {
-    // filters: the bytes the reference would hash are exactly the ASCII of `code` (then the table can answer); otherwise
-    // raw0..2 are those bytes (a query with foreign characters) and only the MPHF path applies.
+__device__ __forceinline__ Probe probe23_wave(const IndexDev& ix, bool want, uint64_t w0, uint64_t w1, uint64_t w2, uint64_t code, bool filters = true,
+                                              bool absence = true) {
     Probe r;
     r.found = false; r.tf = 0; r.slot = 0; r.lines = 0;
-    bool mphf = want;
+    const bool rest = want;
+    uint64_t a = 0, b = 0, c = 0;
+    if (rest) jenkins23(w0, w1, w2, ix.m.seed, a, b, c);
+    bool mphf = rest;
     if (ix.bk) {
-        bool use = want && filters;
-        const uint64_t z = use ? code_mix(code) : 0ull;
+        bool use = rest && filters;
         if (ix.bloom && absence && use) {                       // absent from the filter = not a filed key; an unfiled key (overflow) is in it too
             r.lines += 4096;
-            const uint64_t z2 = code_mix2(z);
-            const uint64_t m = bloom_mask(z2);
-            if ((ix.bloom[bloom_word(z2 >> 24 | z2 << 40, ix.nbloom)] & m) != m) { use = false; mphf = false; }
+            const uint64_t m = bloom_mask(c);
+            if ((ix.bloom[bloom_word(b, ix.nbloom)] & m) != m) { use = false; mphf = false; }
         }
-        const BkRes k = bucket_probe_wave<LPP>(ix.bk, ix.nb, use, z, code);
+        const BkRes k = bucket_probe_wave<LPP>(ix.bk, ix.nb, use, a, code);
         if (use) {
             r.lines += 65536;
             if (k.found) { r.found = true; r.tf = k.tf; r.slot = k.slot; }
             mphf = !k.found && k.overflow;
         }
     }
-    if (mphf) {                                                 // the reference's own route: Jenkins hash of the bytes, MPHF, checker
-        uint64_t s0 = raw0, s1 = raw1, s2 = raw2, a, b, c;
-        if (filters) ascii23_of_rc(revcomp(code, 23), s0, s1, s2);
-        jenkins23(s0, s1, s2, ix.m.seed, a, b, c);
+    if (mphf) {
         const Probe q = probe23_mphf(ix, a, b, c, code, filters);
         r.found = q.found; r.tf = q.tf; r.slot = q.slot; r.lines += q.lines;
     }
@@ -137,7 +134,9 @@ __device__ __forceinline__ Q23 query23(const IndexDev& ix, bool active, uint64_t
         // every stored code is canonical: only the canonical strand of a pure-ACGT query can match. ONE probe call site: with the
         // strands chosen per lane first, a wave runs Jenkins + the probe once, not once per strand with half its lanes idle
         const bool fwd = e.code <= r;
-        const Probe p = probe23_wave<LPP>(ix, active && e.valid, fwd ? e.code : r, true, fg.on, 0, 0, 0);
+        uint64_t x0 = w0, x1 = w1, x2 = w2;
+        if (!fwd) ascii23_of_rc(e.code, x0, x1, x2);
+        const Probe p = probe23_wave<LPP>(ix, active && e.valid, x0, x1, x2, fwd ? e.code : r, true, fg.on);
         fg.seen(active && e.valid, p.found);
         if (active && e.valid) {
             out.lines = p.lines;
@@ -159,8 +158,10 @@ __device__ __forceinline__ Q23 query23(const IndexDev& ix, bool active, uint64_t
         }
         return out;
     }
-    const Probe f = probe23_wave<LPP>(ix, active, e.code, e.valid, fg.on, w0, w1, w2);   // raw bytes hashed, sanitised code compared
-    const Probe g = probe23_wave<LPP>(ix, active && !f.found, r, true, fg.on, 0, 0, 0);  // decode(reverseDNA(u)), :615-616
+    const Probe f = probe23_wave<LPP>(ix, active, w0, w1, w2, e.code, e.valid, fg.on);   // raw bytes hashed, sanitised code compared
+    uint64_t r0, r1, r2;
+    ascii23_of_rc(e.code, r0, r1, r2);                          // decode(reverseDNA(u)), :615-616
+    const Probe g = probe23_wave<LPP>(ix, active && !f.found, r0, r1, r2, r, true, fg.on);
     fg.seen(active, f.found || g.found);
     if (active) {
         out.lines = f.lines;
@@ -198,9 +199,12 @@ __device__ __forceinline__ void both23(const IndexDev& ix, bool active, uint64_t
         }
         return;
     }
-    const Probe F = probe23_wave<LPP>(ix, slow, e.code, e.valid, fg.on, w0, w1, w2);
-    const Probe R = probe23_wave<LPP>(ix, slow, r, true, fg.on, 0, 0, 0);
-    const Probe S2 = probe23_wave<LPP>(ix, slow && !e.valid, e.code, true, fg.on, 0, 0, 0);
+    uint64_t r0, r1, r2, s0, s1, s2;
+    ascii23_of_rc(e.code, r0, r1, r2);
+    ascii23_of_rc(r, s0, s1, s2);
+    const Probe F = probe23_wave<LPP>(ix, slow, w0, w1, w2, e.code, e.valid, fg.on);
+    const Probe R = probe23_wave<LPP>(ix, slow, r0, r1, r2, r, true, fg.on);
+    const Probe S2 = probe23_wave<LPP>(ix, slow && !e.valid, s0, s1, s2, e.code, true, fg.on);
     fg.seen(slow, F.found || R.found);
     if (slow) {
         const Probe S = e.valid ? F : S2;
@@ -263,15 +267,19 @@ __global__ void __launch_bounds__(kBlock) k_lookup23_codes(const IndexDev ix_, c
         const bool in = i < N;
         const uint64_t u = in ? (codes[i] & ((1ULL << 46) - 1)) : 0ull;
         const uint64_t r = revcomp(u, 23);
+        uint64_t w0, w1, w2;
         uint32_t tf = 0;
         if (CANON) {
             const uint64_t key = u <= r ? u : r;
-            const Probe p = probe23_wave<LPP>(ix, in, key, true, fg.on, 0, 0, 0);
+            ascii23_of_rc(u <= r ? r : u, w0, w1, w2);           // string of `key`
+            const Probe p = probe23_wave<LPP>(ix, in, w0, w1, w2, key, true, fg.on);
             fg.seen(in, p.found);
             tf = p.found ? p.tf : 0u;
         } else {
-            const Probe f = probe23_wave<LPP>(ix, in, u, true, fg.on, 0, 0, 0);
-            const Probe g = probe23_wave<LPP>(ix, in && !f.found, r, true, fg.on, 0, 0, 0);
+            ascii23_of_rc(r, w0, w1, w2);
+            const Probe f = probe23_wave<LPP>(ix, in, w0, w1, w2, u, true, fg.on);
+            ascii23_of_rc(u, w0, w1, w2);
+            const Probe g = probe23_wave<LPP>(ix, in && !f.found, w0, w1, w2, r, true, fg.on);
             fg.seen(in, f.found || g.found);
             tf = f.found ? f.tf : (g.found ? g.tf : 0u);
         }
@@ -525,9 +533,8 @@ __global__ void __launch_bounds__(kBlock) k_bk_fill(const MphfDev m, const KeyRe
         ascii23_of_rc(revcomp(kr.code, 23), w0, w1, w2);
         jenkins23(w0, w1, w2, m.seed, a, b, c);
         if (mphf_from_hash(m, a, b, c) != i) continue;         // not where the MPHF puts it: the reference cannot find it, neither can a probe
-        const uint64_t z = code_mix(kr.code);
-        if (bloom) { const uint64_t z2 = code_mix2(z); atomicOr((unsigned long long*)&bloom[bloom_word(z2 >> 24 | z2 << 40, nbloom)], (unsigned long long)bloom_mask(z2)); }
-        const uint32_t bi = bucket_of(z, nb);
+        if (bloom) atomicOr((unsigned long long*)&bloom[bloom_word(b, nbloom)], (unsigned long long)bloom_mask(c));
+        const uint32_t bi = bucket_of(a, nb);
         const uint32_t pos = atomicAdd(&fill[bi], 1u);
         BkEntry e;
         e.code_lo = (uint32_t)kr.code; e.code_hi = (uint32_t)(kr.code >> 32); e.tf = kr.tf; e.slot = (uint32_t)i;
@@ -665,7 +672,9 @@ __global__ void __launch_bounds__(kBlock) k_count23_fixed(const IndexDev ix, con
         uint64_t key = e.code;
         if (canon_mode == 1) { const uint64_t x = revcomp_refx86(e.code, 23); key = e.code < x ? e.code : x; }
         else if (canon_mode == 2) { const uint64_t x = revcomp(e.code, 23); key = e.code < x ? e.code : x; }
-        const Probe pr = probe23_wave<LPP>(ixn, in && e.valid, key, true, false, 0, 0, 0);
+        uint64_t s0, s1, s2;
+        ascii23_of_rc(revcomp(key, 23), s0, s1, s2);
+        const Probe pr = probe23_wave<LPP>(ixn, in && e.valid, s0, s1, s2, key);
         if (pr.found) atomicAdd(&tf_out[pr.slot], 1u);
     }
 }
@@ -691,7 +700,9 @@ __global__ void __launch_bounds__(kBlock) k_probe23_slots(const IndexDev ix, con
         uint64_t key = e.code;
         if (canon_mode == 1) { const uint64_t x = revcomp_refx86(e.code, 23); key = e.code < x ? e.code : x; }
         else if (canon_mode == 2) { const uint64_t x = revcomp(e.code, 23); key = e.code < x ? e.code : x; }
-        const Probe pr = probe23_wave<LPP>(ixn, in && e.valid, key, true, false, 0, 0, 0);
+        uint64_t s0, s1, s2;
+        ascii23_of_rc(revcomp(key, 23), s0, s1, s2);
+        const Probe pr = probe23_wave<LPP>(ixn, in && e.valid, s0, s1, s2, key);
         if (in) slots[p] = pr.found ? (uint32_t)pr.slot : 0xFFFFFFFFu;
     }
 }

@@ -57,19 +57,22 @@ __global__ void __launch_bounds__(kB) k_a2_probe(const IndexDev ix, const uint8_
         const uint64_t r = revcomp(e.code, 23);
         const bool fwd = e.code <= r;                                           // :1032: probe the numerically smaller strand only
         const uint64_t want = fwd ? e.code : r;
-        const bool tab = probe && (e.valid || !fwd);                            // the bytes the reference hashes are the ASCII of `want`
-        bool mphf = probe;
+        uint64_t x0 = w0, x1 = w1, x2 = w2;                                     // forward: the raw bytes of the window
+        if (!fwd) ascii23_of_rc(e.code, x0, x1, x2);
+        const bool tab = probe && (e.valid || !fwd);                            // the hashed bytes are the ASCII of `want`
+        const bool rest = probe;
+        uint64_t a = 0, b = 0, c = 0;
+        if (rest) jenkins23(x0, x1, x2, ix.m.seed, a, b, c);
+        bool mphf = rest;
         if (ix.bk) {
-            const BkRes k = bucket_probe_wave<8>(ix.bk, ix.nb, tab, tab ? code_mix(want) : 0ull, want);
-            if (tab) {
+            const bool use = rest && tab;
+            const BkRes k = bucket_probe_wave<8>(ix.bk, ix.nb, use, a, want);
+            if (use) {
                 if (k.found) key = k.slot;
                 mphf = !k.found && k.overflow;
             }
         }
-        if (mphf) {                                                             // the reference's own route (:1032-1052)
-            uint64_t x0 = w0, x1 = w1, x2 = w2, a, b, c;                        // forward: the raw bytes of the window
-            if (!fwd) ascii23_of_rc(e.code, x0, x1, x2);
-            jenkins23(x0, x1, x2, ix.m.seed, a, b, c);
+        if (mphf) {
             const uint64_t h = mphf_from_hash(ix.m, a, b, c);
             if (h < ix.n && ix.keys[h].code == want) key = (uint32_t)h;
         }
