@@ -91,6 +91,10 @@ SIGNATURES = {
     "aix_positions_bucket_counts": (i32, [vp, vp, u64, i32, vp]),
     "aix_positions_start": (i32, [vp, u64, C.POINTER(u64)]),
     "aix_positions_start_k": (i32, [vp, u64, i32, C.POINTER(u64)]),
+    "aix_index_scatter_shard_codes_dev": (i32, [vp, u64, vp, vp, u64, u64, i32, vp, vp, vp, vp]),
+    "aix_positions_indices_dev": (i32, [vp, vp, vp]),
+    "aix_positions_bucket_counts_dev": (i32, [vp, vp, u64, u64, vp, vp]),
+    "aix_positions_fill_shard_dev": (i32, [vp, vp, u64, u64, u64, vp, vp, vp, vp]),
     "aix_positions_fill_shard": (i32, [vp, vp, u64, i32, u64, vp, vp, u64]),
     "aix_window_codes_dev": (i32, [vp, u64, i32, i32, vp, vp]),
     "aix_normalize_reads": (i32, [vp, u64, i32, i32, vp, C.POINTER(u64)]),

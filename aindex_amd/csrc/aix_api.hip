@@ -1529,6 +1529,54 @@ extern "C" int aix_positions_fill_shard(aix_index_t* h, const char* reads, uint6
 }
 
 // ---------------------------------------------------------------------------------------------
+// device-resident twins of the SHARD entry points (multi-GPU): a rank's share is already in HBM, the partial
+// results stay in HBM for the collectives (RCCL), nothing crosses PCIe
+// ---------------------------------------------------------------------------------------------
+extern "C" int aix_index_scatter_shard_codes_dev(const void* pf_bytes, uint64_t pf_len, const uint64_t* d_codes, const uint32_t* d_counts, uint64_t n_keys,
+                                                 uint64_t n_slots, int device, void* stream, uint64_t* d_checker_out, uint32_t* d_tf_out, uint32_t* d_occupied_out) {
+    if (!pf_bytes || (n_keys && !d_codes) || !d_checker_out || !d_tf_out || !d_occupied_out || n_slots == 0 || n_keys > n_slots) return AIX_ERR_ARG;
+    if (n_slots >> 32) return AIX_ERR_UNSUPPORTED;
+    int st = check_device(device);
+    if (st) return st;
+    aix_index tmp;
+    tmp.device = device; tmp.k = 23; tmp.n = n_slots;
+    DevGuard g(device);
+    st = upload_mphf(&tmp, (const uint8_t*)pf_bytes, pf_len);
+    if (!st) st = scatter_device(&tmp, n_keys, n_slots, nullptr, d_codes, d_counts, d_checker_out, d_tf_out, d_occupied_out, (hipStream_t)stream);
+    if (tmp.recs) { (void)hipStreamSynchronize((hipStream_t)stream); (void)hipFree(tmp.recs); }
+    tmp.recs = nullptr;
+    return st;
+}
+
+extern "C" int aix_positions_indices_dev(aix_index_t* h, uint64_t* d_indices_out, void* stream) {
+    if (!h || !d_indices_out) return AIX_ERR_ARG;
+    DevGuard g(h->device);
+    if (h->n == 0) { HIPCHK(hipMemsetAsync(d_indices_out, 0, 8, (hipStream_t)stream)); return AIX_OK; }
+    HIPCHK(positions_indices(h->dev(), d_indices_out, (hipStream_t)stream));
+    return AIX_OK;
+}
+
+extern "C" int aix_positions_bucket_counts_dev(aix_index_t* h, const char* d_reads, uint64_t len, uint64_t start, uint64_t* d_counts_out, void* stream) {
+    if (!h || !d_counts_out || (len && !d_reads)) return AIX_ERR_ARG;
+    DevGuard g(h->device);
+    if (h->n == 0) return AIX_OK;
+    HIPCHK(hipMemsetAsync(d_counts_out, 0, 8 * h->n, (hipStream_t)stream));
+    HIPCHK(positions_bucket_counts(h->dev(), (const uint8_t*)d_reads, len, start, (unsigned long long*)d_counts_out, (hipStream_t)stream));
+    return AIX_OK;
+}
+
+extern "C" int aix_positions_fill_shard_dev(aix_index_t* h, const char* d_reads, uint64_t len, uint64_t start, uint64_t base_offset, const uint32_t* d_filled_init,
+                                            const uint64_t* d_indices, uint64_t* d_positions, void* stream) {
+    if (!h || !d_indices || !d_positions || (len && !d_reads)) return AIX_ERR_ARG;
+    DevGuard g(h->device);
+    if (h->n == 0) return AIX_OK;
+    uint64_t piece = 0;
+    if (const char* e = getenv("AIX_POSITIONS_PIECE")) piece = strtoull(e, nullptr, 10);
+    HIPCHK(positions_fill(h->dev(), (const uint8_t*)d_reads, len, start, d_indices, d_positions, piece, d_filled_init, base_offset, (hipStream_t)stream));
+    return AIX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // K1: distinct canonical k-mers of a sequence file (kmer_counter replacement)
 // ---------------------------------------------------------------------------------------------
 // device-resident twin: the PLAIN buffer is already in HBM; the result stays in HBM inside an opaque object until the caller

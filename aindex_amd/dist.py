@@ -345,3 +345,166 @@ def positions_fill_sharded(index, reads: bytes):
     pt = torch.from_numpy(part.view(np.int64)).to(dev)
     all_reduce_sum_(pt)                                   # every entry is written by exactly one rank
     return indices, pt.cpu().numpy().view(np.uint64)
+
+
+# ---- device-tensor twins of the I1 / A2 shard protocols: a rank's share and its partial results stay in HBM ---------------
+def _active():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or bool(os.environ.get("AIX_FORCE_DIST")))
+
+
+def _all_reduce_(t, op="sum"):
+    """In-place all-reduce of a device tensor. Under "nccl" (RCCL) the tensor never leaves HBM; under "gloo" (the one-GPU
+    rehearsal of the tests) the collective is staged through host memory."""
+    import torch.distributed as dist
+    if not _active():
+        return t
+    rop = {"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX}[op]
+    if t.is_cuda and dist.get_backend() != "nccl":
+        h = t.cpu()
+        dist.all_reduce(h, op=rop)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=rop)
+    return t
+
+
+def _all_gather(t):
+    """List of every rank's tensor (same shape on all ranks), on t's device; staged through host memory under "gloo"."""
+    import torch
+    import torch.distributed as dist
+    if not _active() or dist.get_world_size() == 1:
+        return [t]
+    world = dist.get_world_size()
+    if t.is_cuda and dist.get_backend() != "nccl":
+        h = t.cpu()
+        outs = [torch.empty_like(h) for _ in range(world)]
+        dist.all_gather(outs, h)
+        return [o.to(t.device) for o in outs]
+    outs = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(outs, t)
+    return outs
+
+
+def scatter_sharded_t(pf_bytes: bytes, codes_t, counts_t, n_slots: int):
+    """compute_index over ranks with everything resident: `codes_t` (int64, u64 bit patterns: THIS rank's share of the 2-bit key
+    codes, on its GPU) and `counts_t` (int32 or None) are scattered through the MPHF into zeroed full-size device arrays
+    (aix_index_scatter_shard_codes_dev); the shards are merged where they lie with all_reduce(MAX) on the checker, all_reduce(SUM)
+    on tf and on a one-byte-per-slot occupancy (a slot claimed twice, inside a shard or across shards, is the reference's
+    collision, hash.cpp:703-709). Returns (checker int64[n_slots], tf int32[n_slots]) device tensors on every rank."""
+    import numpy as np
+    import torch
+    from ._lib import lib, vp, AIX_ERR_CONFLICT, check
+    dev = codes_t.device
+    checker = torch.empty(n_slots, dtype=torch.int64, device=dev)
+    tf = torch.empty(n_slots, dtype=torch.int32, device=dev)
+    occ = torch.empty((n_slots + 31) // 32, dtype=torch.int32, device=dev)
+    pf = np.frombuffer(pf_bytes, dtype=np.uint8)
+    nk = codes_t.numel()
+    with torch.cuda.device(dev):
+        st = lib().aix_index_scatter_shard_codes_dev(pf.ctypes.data_as(vp), pf.shape[0], vp(codes_t.data_ptr()) if nk else None,
+                                                     vp(counts_t.data_ptr()) if counts_t is not None and nk else None, nk, n_slots, dev.index,
+                                                     vp(torch.cuda.current_stream(dev).cuda_stream), vp(checker.data_ptr()), vp(tf.data_ptr()),
+                                                     vp(occ.data_ptr()))
+    err = None
+    if st not in (0, AIX_ERR_CONFLICT):             # OOM, HIP error, malformed .pf ...: every rank raises, none is left in a collective
+        try:
+            check(st, "aix_index_scatter_shard_codes_dev")
+        except Exception as e:
+            err = e
+    _raise_together(err, "scatter_sharded_t", dev if not _active() or _backend_is_nccl() else "cpu")
+    bits = ((occ.unsqueeze(1) >> torch.arange(32, device=dev, dtype=torch.int32)) & 1).to(torch.int8).reshape(-1)[:n_slots].contiguous()
+    bad = torch.tensor([1 if st == AIX_ERR_CONFLICT else 0], dtype=torch.int32, device=dev)
+    _all_reduce_(checker, "max")
+    _all_reduce_(tf, "sum")
+    _all_reduce_(bits, "sum")
+    _all_reduce_(bad, "sum")
+    if bool((bits > 1).any().item()) or int(bad.item()):
+        raise RuntimeError("hash conflict while scattering (a key outside the MPHF's key set, or a duplicate key)")
+    return checker, tf
+
+
+def _backend_is_nccl():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
+
+
+def positions_fill_sharded_t(index, shard_t, base_offset: int, merge: str = "all"):
+    """compute_aindex over ranks with everything resident: `shard_t` (uint8, on the index's GPU) is THIS rank's record-aligned
+    share of the reads file, `base_offset` its byte offset inside the file. The per-bucket tallies of every shard (u32 each) are
+    all-gathered on the device, each rank fills its shard with slot numbering continuing from the shards before it, and the
+    full-size partial arrays (one writer per entry, zero elsewhere) are merged in HBM (RCCL under "nccl"):
+      merge="all"     all_reduce(SUM): every rank ends with the whole positions array (== the reference's .index.bin);
+      merge="scatter" reduce_scatter(SUM): rank r ends with the r-th of `world` equal slices of it (half the link traffic; the
+                      slice bounds are returned so that the file can be written by offset).
+    Returns (indices int64[n + 1], positions int64[...], (lo, hi)): positions covers entries [lo, hi) of the whole array."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    from ._lib import lib, vp, check
+    rank, world, _ = rank_world()
+    active = _active()
+    dev = shard_t.device
+    cdev = dev if (not active or _backend_is_nccl()) else "cpu"
+    n, k = index.n, index.k
+    stream = lambda: vp(torch.cuda.current_stream(dev).cuda_stream)
+    # the reference's start adjustment (hash.cpp:973-986) belongs to the beginning of the FILE and carries into the next shard when a
+    # shard holds no clean window: every rank looks at the head of its own shard
+    head_len, start = 1 << 16, C.c_uint64()
+    while True:
+        head = shard_t[:head_len].cpu().numpy()
+        check(lib().aix_positions_start_k(head.ctypes.data_as(vp) if head.shape[0] else None, head.shape[0], k, C.byref(start)), "aix_positions_start_k")
+        if head.shape[0] == shard_t.numel() or start.value + 64 < head.shape[0]:
+            break
+        head_len *= 16
+    exhausted = 1 if (shard_t.numel() < k or start.value >= shard_t.numel() - (k - 1)) else 0
+    exs = _all_gather(torch.tensor([exhausted], dtype=torch.int32, device=cdev))
+    first = all(int(e.item()) == 1 for e in exs[:rank])
+    my_start = start.value if first else 0
+    counts = torch.empty(max(n, 1), dtype=torch.int64, device=dev)[:n]
+    indices = torch.empty(n + 1, dtype=torch.int64, device=dev)
+    err = None
+    with torch.cuda.device(dev):
+        try:
+            check(lib().aix_positions_bucket_counts_dev(index._h, vp(shard_t.data_ptr()) if shard_t.numel() else None, shard_t.numel(), my_start,
+                                                        vp(counts.data_ptr()), stream()), "aix_positions_bucket_counts_dev")
+            check(lib().aix_positions_indices_dev(index._h, vp(indices.data_ptr()), stream()), "aix_positions_indices_dev")
+        except Exception as e:
+            err = e
+    _raise_together(err, "positions_fill_sharded_t (tally)", cdev)
+    # a shard's tally of one bucket never exceeds the bucket's tf (u32): 4 bytes per bucket and rank cross the links
+    allc = _all_gather(_u32_bits(counts))
+    before = torch.zeros_like(counts)
+    for r in range(rank):
+        before += allc[r].to(torch.int64) & 0xFFFFFFFF
+    filled32 = _u32_bits(before)
+    total = int(indices[-1].item())
+    per = (total + world - 1) // world if merge == "scatter" else total
+    pos = torch.zeros(max(per * world if merge == "scatter" else total, 1), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        try:
+            if total:
+                check(lib().aix_positions_fill_shard_dev(index._h, vp(shard_t.data_ptr()) if shard_t.numel() else None, shard_t.numel(), my_start, base_offset,
+                                                         vp(filled32.data_ptr()), vp(indices.data_ptr()), vp(pos.data_ptr()), stream()),
+                      "aix_positions_fill_shard_dev")
+        except Exception as e:
+            err = e
+    _raise_together(err, "positions_fill_sharded_t (fill)", cdev)
+    if merge == "scatter" and active and world > 1:
+        if _backend_is_nccl():
+            mine = torch.empty(per, dtype=torch.int64, device=dev)
+            dist.reduce_scatter_tensor(mine, pos, op=dist.ReduceOp.SUM)
+        else:                                                # gloo has no reduce-scatter: the rehearsal sums everything and cuts
+            mine = _all_reduce_(pos, "sum")[rank * per:(rank + 1) * per]
+        lo = min(rank * per, total)
+        hi = min(lo + per, total)
+        return indices, mine[: hi - lo], (lo, hi)
+    _all_reduce_(pos, "sum")                                # every entry is written by exactly one rank
+    return indices, pos[:total], (0, total)
+
+
+def _u32_bits(t64):
+    """int64 values (clamped to 2^32 - 1) as the int32 tensor with the same low 32 bits (u32 bit patterns)."""
+    import torch
+    v = t64.clamp(min=0, max=(1 << 32) - 1)
+    return torch.where(v >= (1 << 31), v - (1 << 32), v).to(torch.int32).contiguous()

@@ -261,6 +261,19 @@ int aix_positions_start(const char* reads, uint64_t len, uint64_t* start_out);
 int aix_positions_start_k(const char* reads, uint64_t len, int k /* 23 or 13 */, uint64_t* start_out);
 int aix_positions_fill_shard(aix_index_t* h, const char* reads, uint64_t len, int first_shard, uint64_t base_offset,
                              const uint32_t* filled_init, uint64_t* positions_out, uint64_t positions_cap);
+/* Device-resident twins of the SHARD entry points (one process per GPU; the partial results stay in HBM for the RCCL collectives
+ * of aindex_amd/dist.py: scatter_sharded_t, positions_fill_sharded_t). d_* are device pointers; `start` is
+ * aix_positions_start_k() of the shard's head (0 unless the shard is the first one that holds a clean window);
+ * aix_positions_fill_shard_dev writes into a caller-zeroed FULL-size positions array (indices[n] entries). */
+int aix_index_scatter_shard_codes_dev(const void* pf_bytes, uint64_t pf_len, const uint64_t* d_codes, const uint32_t* d_counts /* nullable */,
+                                      uint64_t n_keys, uint64_t n_slots, int device, void* stream, uint64_t* d_checker_out, uint32_t* d_tf_out,
+                                      uint32_t* d_occupied_out /* ceil(n_slots / 32) words */);
+int aix_positions_indices_dev(aix_index_t* h, uint64_t* d_indices_out /* n + 1 */, void* stream);
+int aix_positions_bucket_counts_dev(aix_index_t* h, const char* d_reads, uint64_t len, uint64_t start, uint64_t* d_counts_out /* n, zeroed here */,
+                                    void* stream);
+int aix_positions_fill_shard_dev(aix_index_t* h, const char* d_reads, uint64_t len, uint64_t start, uint64_t base_offset,
+                                 const uint32_t* d_filled_init /* n, nullable */, const uint64_t* d_indices /* n + 1 */,
+                                 uint64_t* d_positions /* indices[n], zeroed by the caller */, void* stream);
 /* K1 complete: replaces `kmer_counter <in.fa> <k> <out> [-t N] [-m min]` (src/count_kmers.cpp:235-382): the set of
  * (canonical k-mer code, count) with count >= min_count, sorted by code ascending (the reference sorts by count with
  * unspecified tie order; parity is on the set). *keys_out / *counts_out are malloc'd (aix_free). format as for the

@@ -57,6 +57,19 @@ def main():
         assert np.array_equal(ind, want_ind) and np.array_equal(pos, want_pos) and (pos != 0).sum() > 1000
         i1, p1 = ix.positions_fill(tricky)
         assert np.array_equal(p1, want_pos)
+        # the same two files with every rank's shard and all partial results resident in HBM (device-tensor protocol):
+        # all-reduce merge (everybody holds the whole array) and reduce-scatter merge (rank r holds the r-th slice)
+        for buf, wi, wp in ((reads, z["indices"], z["index"]), (tricky, want_ind, want_pos)):
+            lo_b, hi_b = adist.shard_line_bounds(buf, rank, world)
+            mine = buf[lo_b:hi_b]
+            st = torch.frombuffer(bytearray(mine) if mine else bytearray(1), dtype=torch.uint8)[: len(mine)].cuda()
+            ind_t, pos_t, (p_lo, p_hi) = adist.positions_fill_sharded_t(ix, st, lo_b)
+            assert (p_lo, p_hi) == (0, wp.shape[0]) and ind_t.is_cuda and pos_t.is_cuda
+            assert np.array_equal(ind_t.cpu().numpy().view(np.uint64), wi) and np.array_equal(pos_t.cpu().numpy().view(np.uint64), wp)
+            ind_t, pos_t, (p_lo, p_hi) = adist.positions_fill_sharded_t(ix, st, lo_b, merge="scatter")
+            assert p_hi - p_lo == pos_t.numel() and np.array_equal(pos_t.cpu().numpy().view(np.uint64), wp[p_lo:p_hi])
+            span = torch.tensor([p_hi - p_lo], dtype=torch.int64, device="cuda:0" if dist.get_backend() == "nccl" else "cpu")
+            assert int(adist.all_reduce_sum_(span).item()) == wp.shape[0]      # the slices tile the array
         cnt = torch.tensor([hi - lo], dtype=torch.int64, device="cuda:0" if dist.get_backend() == "nccl" else "cpu")
         adist.all_reduce_sum_(cnt)
         assert int(cnt.item()) == len(seqs)
@@ -81,6 +94,20 @@ def main():
     try:
         adist.scatter_sharded(open(prefix + ".pf", "rb").read(), bad, full_tf[perm], device=0)
         raise AssertionError("duplicate key not detected")
+    except RuntimeError as e:
+        assert "conflict" in str(e)
+    # the same with the key codes resident: every rank holds ITS share of the codes in HBM, the merged arrays stay there
+    lo_k, hi_k = adist.shard_range(perm.shape[0], rank, world)
+    codes_t = torch.from_numpy(full_checker[perm][lo_k:hi_k].view(np.int64).copy()).cuda()
+    cnt_t = torch.from_numpy(full_tf[perm][lo_k:hi_k].view(np.int32).copy()).cuda()
+    ck_t, tf_t = adist.scatter_sharded_t(open(prefix + ".pf", "rb").read(), codes_t, cnt_t, full_checker.shape[0])
+    assert ck_t.is_cuda and np.array_equal(ck_t.cpu().numpy().view(np.uint64), full_checker) and np.array_equal(tf_t.cpu().numpy().view(np.uint32), full_tf)
+    dup = codes_t.clone()
+    if rank == world - 1:
+        dup[-1] = int(full_checker[perm][0])                                # a key of rank 0's share again: clash across (or inside) shards
+    try:
+        adist.scatter_sharded_t(open(prefix + ".pf", "rb").read(), dup, cnt_t, full_checker.shape[0])
+        raise AssertionError("duplicate key not detected (device twin)")
     except RuntimeError as e:
         assert "conflict" in str(e)
     from pf13 import pf13_path
