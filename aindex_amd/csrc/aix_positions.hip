@@ -200,28 +200,37 @@ hipError_t positions_fill(const IndexDev& ix, const uint8_t* d_reads, uint64_t l
     uint32_t *keys = nullptr, *skeys = nullptr, *svals = nullptr, *first = nullptr, *filled = nullptr;
     void* tmp = nullptr;
     hipError_t e = pool_alloc((void**)&keys, 4 * pw);
-    if (e == hipSuccess) e = pool_alloc((void**)&skeys, 4 * pw);
-    if (e == hipSuccess) e = pool_alloc((void**)&svals, 4 * pw);
-    if (e == hipSuccess) e = pool_alloc((void**)&first, 4 * ix.n);
     if (e == hipSuccess) e = pool_alloc((void**)&filled, 4 * ix.n);
     if (e == hipSuccess) e = filled_init ? hipMemcpyAsync(filled, filled_init, 4 * ix.n, hipMemcpyDeviceToDevice, s) : hipMemsetAsync(filled, 0, 4 * ix.n, s);
     unsigned end_bit = 1;
     while (end_bit < 32 && (ix.n >> end_bit)) ++end_bit;                        // keys are in [0, n]
     size_t tmp_bytes = 0;
     rocprim::counting_iterator<uint32_t> iota(0);
-    if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, skeys, iota, svals, (size_t)pw, 0u, end_bit, s);
-    if (e == hipSuccess) e = pool_alloc(&tmp, tmp_bytes ? tmp_bytes : 1);
     for (uint64_t w0 = 0; e == hipSuccess && w0 < nwin_all; w0 += pw) {
         const uint64_t nwin = std::min(pw, nwin_all - w0);
         const uint64_t rel_start = start > w0 ? start - w0 : 0;               // windows before `start` get no bucket (hash.cpp:973-986)
+        const bool more = w0 + pw < nwin_all;
         launch_a2_probe(ix, d_reads + w0, nwin, rel_start, keys, s);
         e = hipGetLastError();
+        if (e != hipSuccess) break;
+        if (a2_msd_eligible(nwin, ix.n)) {                                      // grouping by MSD partition + per-bucket LDS stage (aix_a2msd.hip)
+            e = a2_msd_place(ix, keys, nwin, base_offset + w0, filled, more, d_indices, d_positions, s);
+            continue;
+        }
+        if (!skeys) {                                                           // short buffers: one stable radix sort of (bucket, offset)
+            e = pool_alloc((void**)&skeys, 4 * pw);
+            if (e == hipSuccess) e = pool_alloc((void**)&svals, 4 * pw);
+            if (e == hipSuccess) e = pool_alloc((void**)&first, 4 * ix.n);
+            if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, skeys, iota, svals, (size_t)pw, 0u, end_bit, s);
+            if (e == hipSuccess) e = pool_alloc(&tmp, tmp_bytes ? tmp_bytes : 1);
+            if (e != hipSuccess) break;
+        }
         size_t tb = tmp_bytes;                                                  // sized for pw >= nwin elements
-        if (e == hipSuccess) e = rocprim::radix_sort_pairs(tmp, tb, keys, skeys, iota, svals, (size_t)nwin, 0u, end_bit, s);
+        e = rocprim::radix_sort_pairs(tmp, tb, keys, skeys, iota, svals, (size_t)nwin, 0u, end_bit, s);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(k_a2_first, dim3(grid_of(nwin)), dim3(kB), 0, s, skeys, nwin, (uint32_t)ix.n, first);
             hipLaunchKernelGGL(k_a2_place, dim3(grid_of(nwin)), dim3(kB), 0, s, ix, skeys, svals, nwin, base_offset + w0, first, filled, d_indices, d_positions);
-            if (w0 + pw < nwin_all) hipLaunchKernelGGL(k_a2_advance, dim3(grid_of(nwin)), dim3(kB), 0, s, skeys, nwin, (uint32_t)ix.n, first, filled);
+            if (more) hipLaunchKernelGGL(k_a2_advance, dim3(grid_of(nwin)), dim3(kB), 0, s, skeys, nwin, (uint32_t)ix.n, first, filled);
             e = hipGetLastError();
         }
     }

@@ -80,16 +80,18 @@ def build_index23(genome_len, rank, world, device, cache_dir, gpu_builder=False)
     return ix, g, keys, counts32, pf
 
 
-def timed_steps(step_fn, steps, warmup, device):
+def timed_steps(step_fn, steps, warmup, device, collective=True):
     """W warm-up steps, then exactly K steps bracketed by barrier + synchronize; per-launch HIP events on
-    torch's current stream (the stream the kernels are launched on)."""
+    torch's current stream (the stream the kernels are launched on). collective=False: a measurement only this rank takes
+    (no barrier, no max over ranks)."""
     import torch
     from aindex_amd import dist as adist
     for _ in range(warmup):
         step_fn()
     torch.cuda.synchronize()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    adist.barrier()
+    if collective:
+        adist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for a, b in evs:
@@ -97,9 +99,10 @@ def timed_steps(step_fn, steps, warmup, device):
         step_fn()
         b.record()
     torch.cuda.synchronize()
-    adist.barrier()
+    if collective:
+        adist.barrier()
     t1 = time.perf_counter()
-    wall = adist.all_reduce_max_float(t1 - t0, device=f"cuda:{device}")
+    wall = adist.all_reduce_max_float(t1 - t0, device=f"cuda:{device}") if collective else t1 - t0
     kern_ms = [a.elapsed_time(b) for a, b in evs]
     return wall, float(np.mean(kern_ms)), kern_ms
 
@@ -528,7 +531,27 @@ def measure_count23_strong(ix, g, rank, world, dev, total_reads, steps, warmup):
     import torch.distributed as dist
     backend = dist.get_backend() if (dist.is_available() and dist.is_initialized()) else "none"
     windows_rank = (hi - lo) * (150 - 22)
+    # N > 1: rank 0 then runs the WHOLE workload alone (same reads, same kernel, no collective) — the 1-GPU rate of this very
+    # metric measured in the same process, and the histogram the sharded + all-reduced one must equal (digest of all tf[] entries)
+    one = None
+    if world > 1 and not os.environ.get("AIX_BENCH_NO_SINGLE"):
+        if rank == 0:
+            try:
+                all_reads = engine.synth_reads_t(41, g, total_reads, 150, rc_half=True, n_rate_ppm=1000, first_read=0)
+                tf1 = torch.zeros(ix.n, dtype=torch.int32, device=f"cuda:{dev}")
+                def step1():
+                    tf1.zero_()
+                    ix.count23_fixed_t(all_reads, _lib.CANON_TRUE_RC, tf1)
+                w1, _, _ = timed_steps(step1, 2, 1, dev, collective=False)
+                d1 = tf_checksum(tf1)
+                one = {"value": total_reads * 2 / w1, "unit": "reads/s", "ms_per_step": w1 / 2 * 1e3, "tf_digest": d1,
+                       "equals_sharded_result": d1 == digest, "note": "rank 0 alone on all reads, after the timed region"}
+                del all_reads, tf1
+            except Exception as e:  # pragma: no cover
+                one = {"error": f"{type(e).__name__}: {e}"}
+        adist.barrier()
     return {"metric": "reads_per_sec_23mer_count_fixed_mphf", "value": total_reads * steps / wall, "unit": "reads/s",
+            **({"same_workload_on_one_gpu": one} if one else {}),
             "scaling": "strong", "total_reads": total_reads, "reads_this_rank": hi - lo, "ms_per_step": wall / steps * 1e3,
             "allreduce_ms": ar_ms, "allreduce_bytes": 4 * ix.n, "collective": f"all_reduce(sum) of int32 tf[{ix.n}]" if backend != "none" else "none (1 rank)",
             "backend": backend, "collective_ranks": world if backend != "none" else 1,
@@ -759,6 +782,7 @@ def main():
                                "total_reads": a.total_reads, "reads_this_rank": r["reads_this_rank"], "index_keys": ix.n, "genome_bp": a.genome,
                                "parallelism": f"reads sharded x{world}, index replicated", "backend": r["backend"], "collective": r["collective"],
                                "collective_ranks": r["collective_ranks"], "one_device_rehearsal": r["one_device_rehearsal"]},
+                    **({"same_workload_on_one_gpu": r["same_workload_on_one_gpu"]} if "same_workload_on_one_gpu" in r else {}),
                     "allreduce_ms": r["allreduce_ms"], "allreduce_bytes": r["allreduce_bytes"], "tf_digest": r["tf_digest"],
                     "windows_counted_all_ranks": r["windows_counted_all_ranks"],
                     "roofline": {**count23_roofline(ix, r["windows_this_rank"], r["reads_this_rank"], r["kernel_ms_this_rank"]),

@@ -458,6 +458,73 @@ def test_positions_fill_in_pieces(ix23, gold, small23_prefix, canon_case, piece)
         del os.environ["AIX_POSITIONS_PIECE"]
 
 
+@pytest.mark.parametrize("cap", [0, 40, 3])
+def test_positions_fill_msd_path_equals_sort_path_and_oracle(ix23, gold, small23_prefix, canon_case, tmp_path, cap):
+    """A2 without the library sort (aix_a2msd.hip: two-level MSD partition of the (bucket, offset) pairs + per-bucket LDS stage)
+    is the default from 2^22 windows up; AIX_A2_MSD=1 forces it at test sizes, AIX_A2_TEST_CAP shrinks what a bucket may hold in
+    LDS so that buckets are set aside and take the gather + radix-sort path (cap 3: nearly all of them). Every variant must give
+    the reference's 1-thread files (golden), the oracle (tf-capped buckets, repeats, start quirk, separators, lower case), also
+    piece by piece (fill counters carried over), and a slot with hundreds of pairs (cooperative in-LDS sort) with tf above and
+    below its occurrences."""
+    env = {"AIX_A2_MSD": "1"}
+    if cap:
+        env["AIX_A2_TEST_CAP"] = str(cap)
+    os.environ.update(env)
+    try:
+        z = np.load(os.path.join(gold, "small23", "aindex.npz"))
+        reads = open(small23_prefix + ".reads", "rb").read()
+        indices, pos = ix23.positions_fill(reads)
+        assert np.array_equal(indices, z["indices"]) and np.array_equal(pos, z["index"])
+        ix, orc = canon_case["ix"], canon_case["orc"]
+        asc = synth.genome_ascii(23, 300_000)
+        r = synth.reads_plain(47, asc, 3000, 150, rc_fraction_half=True, n_rate_ppm=2000).reshape(-1, 151).copy()
+        r[::7, 150] = ord("~")
+        r[5::50, 10] = ord("?")
+        r[3::40] |= 0x20
+        r[3::40, 150] = ord("\n")
+        buf = b"?AC\n" + r.tobytes() + r[:900].tobytes()                  # repeated reads overflow their buckets (slot >= tf is dropped)
+        want_ind, want_pos = orc.positions(buf)
+        indices, pos = ix.positions_fill(buf)
+        assert np.array_equal(indices, want_ind) and np.array_equal(pos, want_pos) and (pos != 0).sum() > 100_000
+        os.environ["AIX_POSITIONS_PIECE"] = "70000"
+        try:
+            indices, pos = ix.positions_fill(buf)
+        finally:
+            del os.environ["AIX_POSITIONS_PIECE"]
+        assert np.array_equal(pos, want_pos)
+        # heavy slots: one read 700 times (its k-mers: 700 pairs each), tf raised to 1000 for half of them and to 150 for the rest
+        prefix = canon_case["prefix"]
+        checker = np.fromfile(prefix + ".kmers.bin", dtype=np.uint64)
+        tf = np.fromfile(prefix + ".tf.bin", dtype=np.uint32)
+        one = r[11:12].copy()
+        one[0, :150] = np.frombuffer(asc[1000:1150].tobytes(), dtype=np.uint8)
+        one[0, 150] = ord("\n")
+        codes = synth.encode_kmers(np.lib.stride_tricks.sliding_window_view(one[0, :150], 23))
+        canon = np.minimum(codes, synth.revcomp_codes(codes, 23))
+        slots = np.flatnonzero(np.isin(checker, canon))
+        assert slots.shape[0] == 128
+        tf2 = tf.copy()
+        tf2[slots[::2]] = 1000
+        tf2[slots[1::2]] = 150
+        p2 = str(tmp_path / "heavy")
+        import shutil
+        shutil.copy(prefix + ".pf", p2 + ".pf")
+        checker.tofile(p2 + ".kmers.bin")
+        tf2.tofile(p2 + ".tf.bin")
+        orc2 = O.OracleIndex23.from_prefix(p2)
+        heavy = r[:500].tobytes() + one.tobytes() * 700 + r[500:800].tobytes()
+        want_ind, want_pos = orc2.positions(heavy)
+        with Index.open_23(p2 + ".pf", p2 + ".tf.bin", p2 + ".kmers.bin") as ixh:
+            indices, pos = ixh.positions_fill(heavy)
+            assert np.array_equal(indices, want_ind) and np.array_equal(pos, want_pos)
+            os.environ["AIX_A2_MSD"] = "0"                                 # and the sort path on the same input
+            i0, p0 = ixh.positions_fill(heavy)
+            assert np.array_equal(p0, want_pos)
+    finally:
+        for k in list(env) + ["AIX_A2_MSD"]:
+            os.environ.pop(k, None)
+
+
 @pytest.mark.parametrize("world", [2, 3, 5])
 def test_positions_fill_shards_equal_whole(canon_case, world):
     """The two-pass shard protocol of dist.positions_fill_sharded, run rank by rank in one process: per-shard bucket
