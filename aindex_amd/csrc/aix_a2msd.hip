@@ -58,12 +58,14 @@ __global__ void __launch_bounds__(A2_FB) k_a2_final(const IndexDev ix, const uin
                                                    uint32_t rbits, uint32_t cap_e, uint64_t piece_first, uint32_t* __restrict__ filled, int advance,
                                                    const uint64_t* __restrict__ indices, uint64_t* __restrict__ positions, A2Over* __restrict__ over,
                                                    uint32_t* __restrict__ over_b, uint64_t* __restrict__ over_off) {
-    __shared__ uint32_t hist[A2_R];                   // pairs per slot of the bucket
+    __shared__ uint32_t hist2[2][A2_R];               // pairs per slot of the bucket; two copies: the one of the NEXT bucket is cleared while this one is read
     __shared__ uint32_t cursor[A2_R];                 // exclusive scan of hist; after the grouping pass: the END of every slot's run
     __shared__ uint32_t binlim[A2_R];                 // slots still free in the slot's positions range: tf[h] - filled[h]
     __shared__ uint64_t binbase[A2_R];                // indices[h] + filled[h]
-    __shared__ uint32_t offs[A2_CAP];                 // window offsets grouped by slot
+    __shared__ __attribute__((aligned(16))) uint32_t offs[A2_CAP + 4];      // window offsets grouped by slot
     __shared__ uint32_t wsum[A2_FB / 64];
+    __shared__ uint32_t heavy_n[2];                   // slots of the bucket with more than A2_HEAVY pairs (cleared with hist2)
+    __shared__ uint32_t heavy_s[2][A2_CAP / A2_HEAVY];
     const uint32_t t = threadIdx.x, R = 1u << rbits, n = (uint32_t)ix.n;
     const bool k13 = ix.k == 13;
     constexpr int SPT = A2_R / A2_FB;                 // slots a lane owns in the scan
@@ -93,6 +95,10 @@ __global__ void __launch_bounds__(A2_FB) k_a2_final(const IndexDev ix, const uin
         }
     };
     prefetch(blockIdx.x);
+    for (uint32_t i = t; i < R; i += A2_FB) { hist2[0][i] = 0; hist2[1][i] = 0; }
+    if (t < 2) heavy_n[t] = 0;
+    __syncthreads();
+    uint32_t par = 0;                                 // which copy of hist this bucket uses (uniform)
     for (uint32_t b = blockIdx.x; b < nbuckets; b += gridDim.x) {
         const uint32_t lo = n_lo, n_e_cnt = n_n;
         uint64_t e[A2_PRE], s_ind[SPT], s_tf[SPT];
@@ -112,42 +118,62 @@ __global__ void __launch_bounds__(A2_FB) k_a2_final(const IndexDev ix, const uin
             }
             continue;
         }
+        uint32_t* hist = hist2[par];
         // the usual bucket (<= 1024 pairs) lives in registers; the tail of a fuller one is re-read (it is in L2: level 2 has just written it)
-        for (uint32_t i = t; i < R; i += A2_FB) hist[i] = 0;
-        __syncthreads();
 #pragma unroll
         for (int q = 0; q < A2_PRE; ++q)
             if (e[q] != ~0ull) atomicAdd(&hist[(uint32_t)(e[q] >> 32)], 1u);
         for (uint32_t i = t + A2_PRE * A2_FB; i < n_e; i += A2_FB) atomicAdd(&hist[(uint32_t)(rem[lo + i] >> 32)], 1u);
-        __syncthreads();
-        // scan: a lane owns SPT consecutive slots and publishes their output ranges
+        __syncthreads();                                           // also: every wave has left the previous bucket
+        // scan: a lane owns SPT consecutive slots and publishes their output ranges. Every slot's run starts at a multiple of four
+        // entries and is padded with +infinity, so that the ranking below reads whole 16-byte vectors and needs no index masks
         uint32_t c4[SPT], sum = 0;
 #pragma unroll
-        for (int j = 0; j < SPT; ++j) { const uint32_t s = SPT * t + j; c4[j] = s < R ? hist[s] : 0u; sum += c4[j]; }
+        for (int j = 0; j < SPT; ++j) { const uint32_t s = SPT * t + j; c4[j] = s < R ? hist[s] : 0u; sum += (c4[j] + 3u) & ~3u; }
         uint32_t sc = sum;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(sc, d); if ((t & 63) >= d) sc += y; }
         if ((t & 63) == 63) wsum[t >> 6] = sc;
-#pragma unroll
-        for (int j = 0; j < SPT; ++j) {
-            const uint32_t s = SPT * t + j;
-            const uint64_t h = ((uint64_t)b << rbits) | s;
-            if (c4[j] && h < n) {
-                const uint32_t fl = s_fl[j];
-                binbase[s] = s_ind[j] + fl;
-                const uint64_t room = s_tf[j] > fl ? s_tf[j] - fl : 0ull;
-                binlim[s] = room > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)room;
-                if (advance) { const uint64_t tot = (uint64_t)fl + c4[j]; filled[h] = tot > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)tot; }
-            } else if (s < R) {
-                binlim[s] = 0;
-            }
-        }
+        // the other copy of the histogram was last read while the previous bucket was placed: clear it for the next one
+        for (uint32_t i = t; i < R; i += A2_FB) hist2[par ^ 1][i] = 0;
+        if (t == 0) heavy_n[par ^ 1] = 0;
         __syncthreads();
+        uint32_t padded = 0;
+#pragma unroll
+        for (int w = 0; w < A2_FB / 64; ++w) padded += wsum[w];
+        if (padded > (uint32_t)A2_CAP) {                           // the padding does not fit (many sparsely used slots in a full bucket): set aside
+            if (t == 0) {
+                const uint32_t idx = atomicAdd(&over->n, 1u);
+                over_b[idx] = b;
+                over_off[idx] = atomicAdd(&over->elems, (unsigned long long)n_e);
+            }
+            par ^= 1;
+            continue;
+        }
         {
             uint32_t off = sc - sum;
             for (uint32_t w = 0; w < (t >> 6); ++w) off += wsum[w];
 #pragma unroll
-            for (int j = 0; j < SPT; ++j) { const uint32_t s = SPT * t + j; if (s < R) cursor[s] = off; off += c4[j]; }
+            for (int j = 0; j < SPT; ++j) {
+                const uint32_t s = SPT * t + j;
+                const uint64_t h = ((uint64_t)b << rbits) | s;
+                if (s < R) {
+                    cursor[s] = off;
+                    const uint32_t c = c4[j], cr = (c + 3u) & ~3u;
+                    for (uint32_t i = c; i < cr; ++i) offs[off + i] = 0xFFFFFFFFu;
+                    uint32_t lim = 0;
+                    if (c && h < n) {
+                        const uint32_t fl = s_fl[j];
+                        binbase[s] = s_ind[j] + fl;
+                        const uint64_t room = s_tf[j] > fl ? s_tf[j] - fl : 0ull;
+                        lim = room > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)room;
+                        if (advance) { const uint64_t tot = (uint64_t)fl + c; filled[h] = tot > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)tot; }
+                        if (c > (uint32_t)A2_HEAVY) heavy_s[par][atomicAdd(&heavy_n[par], 1u)] = s;
+                    }
+                    binlim[s] = lim;
+                    off += cr;
+                }
+            }
         }
         __syncthreads();
         // grouping: any order inside a slot's run (the order is recovered from the offsets below)
@@ -159,9 +185,9 @@ __global__ void __launch_bounds__(A2_FB) k_a2_final(const IndexDev ix, const uin
         // a slot with many pairs (a k-mer repeated hundreds of times inside this piece): its run is sorted in place by the whole
         // workgroup — a bitonic network whose compare-exchanges all point upwards, so that runs of any length need no padding
         // (a partner index past the run is a virtual +infinity that would never move) — and placed straight from the sorted run
-        for (uint32_t s = 0; s < R; ++s) {                         // uniform: hist[s] is the same for every lane
-            const uint32_t cnt = hist[s];
-            if (cnt <= (uint32_t)A2_HEAVY) continue;
+        const uint32_t nheavy = heavy_n[par];                      // uniform
+        for (uint32_t hi = 0; hi < nheavy; ++hi) {
+            const uint32_t s = heavy_s[par][hi], cnt = hist[s];
             uint32_t* run = offs + (cursor[s] - cnt);
             uint32_t half_p = 1;
             while (2 * half_p < cnt) half_p <<= 1;                 // pairs per step = P / 2, P = the power of two >= cnt
@@ -187,19 +213,23 @@ __global__ void __launch_bounds__(A2_FB) k_a2_final(const IndexDev ix, const uin
             const uint64_t base = binbase[s];
             for (uint32_t i = t; i < lim; i += A2_FB) positions[base + i] = piece_first + run[i] + 1;
         }
+        // every other pair ranks itself among the offsets of its slot (four per LDS read): ascending offsets = the reference's arrival order
         auto place = [&](uint64_t x) {
             const uint32_t s = (uint32_t)(x >> 32), off = (uint32_t)x;
-            const uint32_t cnt = hist[s], first = cursor[s] - cnt;
+            const uint32_t cnt = hist[s], end = cursor[s], first = end - cnt;
             if (cnt > (uint32_t)A2_HEAVY) return;                                                  // placed above
             uint32_t rank = 0;
-            for (uint32_t j = 0; j < cnt; ++j) rank += offs[first + j] < off ? 1u : 0u;            // ascending offsets = the reference's arrival order
+            for (uint32_t q = first; q < end; q += 4) {                                            // `first` is a multiple of four, the run is padded with +infinity
+                const uint4 v = *reinterpret_cast<const uint4*>(&offs[q]);
+                rank += (v.x < off ? 1u : 0u) + (v.y < off ? 1u : 0u) + (v.z < off ? 1u : 0u) + (v.w < off ? 1u : 0u);
+            }
             if (rank < binlim[s]) positions[binbase[s] + rank] = piece_first + off + 1;          // hash.cpp:1037-1040, 1-based
         };
 #pragma unroll
         for (int q = 0; q < A2_PRE; ++q)
             if (e[q] != ~0ull) place(e[q]);
         for (uint32_t i = t + A2_PRE * A2_FB; i < n_e; i += A2_FB) place(rem[lo + i]);
-        __syncthreads();
+        par ^= 1;
     }
 }
 

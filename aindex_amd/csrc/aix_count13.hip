@@ -59,31 +59,42 @@ __device__ __forceinline__ void for_each_window13(const RUN& r, F&& f) {
     }
 }
 
-__device__ __forceinline__ Run13 encode_run13(const uint8_t* __restrict__ buf, uint64_t len, uint64_t S) {
-    constexpr int NB = C13_WPT + 12;                  // 44 bytes
-    constexpr int ND = NB / 4;                        // 11 aligned dwords
-    Run13 r{{0, 0, 0}, 0};
+// The 44 bytes behind window start S as eleven dwords (bytes at and past `len` read as separators); fetched on their own so that
+// the split kernel can have the NEXT tile's loads in flight while it writes the current one out.
+struct Raw13 {
+    uint32_t e[(C13_WPT + 12) / 4];
+    uint64_t limit;                                   // bytes available from S (0: nothing)
+};
+__device__ __forceinline__ Raw13 fetch_raw13(const uint8_t* __restrict__ buf, uint64_t len, uint64_t S) {
+    constexpr int ND = (C13_WPT + 12) / 4;            // 11 aligned dwords
+    Raw13 r;
+    r.limit = S < len ? len - S : 0;
+#pragma unroll
+    for (int k = 0; k < ND; ++k) r.e[k] = 0x0A0A0A0Au;
     if (S >= len) return r;
-    const uint64_t limit = len - S;                   // bytes available from S
-    uint32_t e[ND];
-    {
-        const uint32_t o = (uint32_t)((uintptr_t)(buf + S) & 3);
-        const uint32_t* q = (const uint32_t*)(buf + S - o);           // pointer arithmetic keeps these global_load (not flat_load)
-        const int64_t first = (int64_t)S - o, end = (int64_t)len;     // byte offset of d[0] from buf (>= -3)
-        uint32_t d[ND + 1];
+    const uint32_t o = (uint32_t)((uintptr_t)(buf + S) & 3);
+    const uint32_t* q = (const uint32_t*)(buf + S - o);           // pointer arithmetic keeps these global_load (not flat_load)
+    const int64_t first = (int64_t)S - o, end = (int64_t)len;     // byte offset of d[0] from buf (>= -3)
+    uint32_t d[ND + 1];
 #pragma unroll
-        for (int k = 0; k <= ND; ++k) d[k] = (first + 4 * k < end) ? q[k] : 0x0A0A0A0Au;   // never read a dword past the buffer
-        const uint32_t sh = o * 8;
+    for (int k = 0; k <= ND; ++k) d[k] = (first + 4 * k < end) ? q[k] : 0x0A0A0A0Au;   // never read a dword past the buffer
+    const uint32_t sh = o * 8;
 #pragma unroll
-        for (int k = 0; k < ND; ++k) e[k] = __funnelshift_r(d[k], d[k + 1], sh);
-    }
+    for (int k = 0; k < ND; ++k) r.e[k] = __funnelshift_r(d[k], d[k + 1], sh);
+    return r;
+}
+__device__ __forceinline__ Run13 encode_raw13(const Raw13& raw) {
+    constexpr int NB = C13_WPT + 12;                  // 44 bytes
+    constexpr int ND = NB / 4;
+    Run13 r{{0, 0, 0}, 0};
+    if (raw.limit == 0) return r;
     // Four bytes at a time (the VALU issues one wave instruction per clock per CU, and the byte-serial form of this loop
     // was ~2/3 of the kernel): x = upper-cased bytes; v = 2-bit value of every byte; a byte is a base iff it equals the
     // letter its own 2-bit value maps back to (v_perm_b32 as the 4-entry table); q = the four values packed first-base-high.
     uint64_t vmask = 0;                               // bit i: byte i is A/C/G/T (either case)
 #pragma unroll
     for (int k = 0; k < ND; ++k) {
-        const uint32_t x = e[k] & 0xDFDFDFDFu;
+        const uint32_t x = raw.e[k] & 0xDFDFDFDFu;
         const uint32_t v = ((x >> 1) ^ (x >> 2)) & 0x03030303u;
         const uint32_t diff = x ^ lut4(v, AIX_LUT_ACGT);
         const uint32_t z = ~(((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff | 0x7F7F7F7Fu);      // 0x80 in every byte where diff == 0
@@ -93,7 +104,7 @@ __device__ __forceinline__ Run13 encode_run13(const uint8_t* __restrict__ buf, u
         r.w[k >> 2] |= q << (24 - 8 * (k & 3));
         vmask |= (uint64_t)nib << (4 * k);
     }
-    if (limit < (uint64_t)NB) vmask &= (1ull << limit) - 1;           // bytes at and past the end of the buffer are separators
+    if (raw.limit < (uint64_t)NB) vmask &= (1ull << raw.limit) - 1;   // bytes at and past the end of the buffer are separators
     // window j (bytes j..j+12) is countable iff 13 consecutive mask bits are set
     const uint64_t m2 = vmask & (vmask >> 1), m4 = m2 & (m2 >> 2), m8 = m4 & (m4 >> 4);
     r.valid = (uint32_t)(m8 & (m4 >> 8) & (vmask >> 12));
@@ -104,7 +115,8 @@ __device__ __forceinline__ Run13 encode_run13(const uint8_t* __restrict__ buf, u
 struct Src13 {                                        // the 13-mer windows of a PLAIN reads buffer (count_kmers13)
     const uint8_t* buf;
     uint64_t len;
-    __device__ __forceinline__ Run13 load(uint64_t tile, int t) const { return encode_run13(buf, len, tile * C13_TILE + (uint64_t)t * C13_WPT); }
+    __device__ __forceinline__ Raw13 fetch(uint64_t tile, int t) const { return fetch_raw13(buf, len, tile * C13_TILE + (uint64_t)t * C13_WPT); }
+    __device__ __forceinline__ Run13 decode(const Raw13& raw) const { return encode_raw13(raw); }
 };
 struct RunSlots {                                     // element j of this lane = p[j * 1024]: every load instruction of the workgroup reads 4 KiB of
     const uint32_t* p;                                // consecutive slots. Nothing is kept in registers between the two passes of the tile sort
@@ -119,13 +131,14 @@ struct RunSlots {                                     // element j of this lane 
 struct SrcSlots {                                     // a stream of MPHF slots (< 2^26) in HBM, 0xFFFFFFFF = nothing to count (count23)
     const uint32_t* slots;
     uint64_t n;
-    __device__ __forceinline__ RunSlots load(uint64_t tile, int t) const {
+    __device__ __forceinline__ RunSlots fetch(uint64_t tile, int t) const {      // nothing is fetched ahead: the passes read the stream themselves
         const uint64_t base = tile * C13_TILE + (uint64_t)t;
         RunSlots r;
         r.p = slots + base;
         r.limit = base < n ? (uint32_t)min((uint64_t)C13_TILE, n - base) : 0u;   // elements [0, limit) of p are inside the stream
         return r;
     }
+    __device__ __forceinline__ RunSlots decode(const RunSlots& r) const { return r; }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -143,39 +156,42 @@ static constexpr int C13_FILLBITS = 9;                // cursor = (chunk << 9) |
 // out with the same block scan that orders the tile (the per-partition chunk demand rides in the high half of the scan).
 // A chunk id at or past `region` cannot happen while chunk_region() is right; if it ever does, the write is dropped AND `err`
 // is raised, so the call fails with AIX_ERR_UNSUPPORTED instead of returning short counts.
-template <class SRC>
+template <class SRC, bool PREFETCH>
 __global__ void __launch_bounds__(C13_TB) k_c13_split_chunked(const SRC src, uint64_t ntiles, uint32_t region,
                                                              uint16_t* __restrict__ dir_part, uint16_t* __restrict__ dir_cnt, uint16_t* __restrict__ parts,
                                                              uint32_t* __restrict__ err) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint32_t* hist = (uint32_t*)smem;                           // [P + DUMMY] tile-local count per partition; after the scan: first NEW chunk of the partition
-    uint32_t* loc_off = hist + C13_P + C13_DUMMY;               // [P] exclusive scan of hist
-    uint32_t* cursor = loc_off + C13_P;                         // [P] (current chunk << 9) | entries used in it (256 = none / full)
-    uint32_t* wsum = cursor + C13_P;                            // [16] per-wave totals: entries (low 16 bits, <= 32768), new chunks (high 16 bits, <= 2176)
+    uint32_t* hist = (uint32_t*)smem;                           // [P + DUMMY] tile-local count per partition; after the scan: write-out delta A of the partition
+    uint32_t* loc_t = hist + C13_P + C13_DUMMY;                 // [P] exclusive scan of hist (low half) | first tile index that no longer fits the current chunk (high half)
+    uint32_t* delta_b = loc_t + C13_P;                          // [P] write-out delta B of the partition (entries that spill into its fresh chunks)
+    uint32_t* wsum = delta_b + C13_P;                           // [16] per-wave totals: entries (low 16 bits, <= 32768), new chunks (high 16 bits, <= 2176)
     uint32_t* sorted = wsum + 16;                               // [TILE] (partition << 16) | low 15 bits, grouped by partition
     const int t = threadIdx.x;
     constexpr uint32_t FILLMASK = (1u << C13_FILLBITS) - 1;
     const uint32_t region_base = blockIdx.x * region;           // chunk ids below are relative to it
     uint32_t next_chunk = 0;                                    // same value in every lane
-    cursor[2 * t] = C13_CH;
-    cursor[2 * t + 1] = C13_CH;
+    // this lane owns partitions 2t and 2t+1 for the whole kernel: their cursors, (current chunk << 9) | entries used in it (256 = none / full),
+    // never leave its registers
+    uint32_t cur0 = C13_CH, cur1 = C13_CH;
     hist[2 * t] = 0;
     hist[2 * t + 1] = 0;
     if (t < C13_DUMMY) hist[C13_P + t] = 0;
     __syncthreads();
+    auto raw = src.fetch(blockIdx.x, t);
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         uint32_t rank[C13_WPT / 2];                              // two 16-bit ranks per register
-        const auto run = src.load(tile, t);
+        if constexpr (!PREFETCH) raw = src.fetch(tile, t);
+        const auto run = src.decode(raw);
         const uint32_t dummy = C13_P + (t & (C13_DUMMY - 1));
         for_each_window13<0>(run, [&](int j, uint32_t code, uint32_t ok) {
             const uint32_t r = atomicAdd(&hist[ok ? code >> C13_BINBITS : dummy], 1u);
             if (j & 1) rank[j >> 1] |= r << 16; else rank[j >> 1] = r;
         });
         __syncthreads();
-        // this lane owns partitions 2t and 2t+1: entries a, b; fresh chunks k0, k1 = by how much they overflow the current chunk
+        // entries a, b of the two partitions this lane owns; fresh chunks k0, k1 = by how much they overflow the current chunk
         const uint32_t a = hist[2 * t], b = hist[2 * t + 1];
-        const uint32_t c0 = cursor[2 * t], c1 = cursor[2 * t + 1];
-        const uint32_t tot0 = (c0 & FILLMASK) + a, tot1 = (c1 & FILLMASK) + b;
+        const uint32_t f0 = cur0 & FILLMASK, f1 = cur1 & FILLMASK;
+        const uint32_t tot0 = f0 + a, tot1 = f1 + b;
         const uint32_t k0 = tot0 > (uint32_t)C13_CH ? (tot0 - 1) / C13_CH : 0u;    // = ceil((tot - CH) / CH)
         const uint32_t k1 = tot1 > (uint32_t)C13_CH ? (tot1 - 1) / C13_CH : 0u;
         uint32_t s = (a + b) | ((k0 + k1) << 16);               // one scan for both: a tile has <= 32768 entries and needs <= 2176 fresh chunks
@@ -193,55 +209,58 @@ __global__ void __launch_bounds__(C13_TB) k_c13_split_chunked(const SRC src, uin
             if (w < (t >> 6)) off += x;
             all += x;
         }
-        const uint32_t excl = off + s - mine;
-        const uint32_t e0 = excl & 0xFFFFu, nb0 = next_chunk + (excl >> 16), nb1 = nb0 + k0;
-        loc_off[2 * t] = e0;
-        loc_off[2 * t + 1] = e0 + a;
-        hist[2 * t] = nb0;
-        hist[2 * t + 1] = nb1;
-        for (uint32_t i = 0; i < k0; ++i) { if (nb0 + i < region) dir_part[region_base + nb0 + i] = (uint16_t)(2 * t); else *err = 1u; }       // fill stays at the pre-set 256
-        for (uint32_t i = 0; i < k1; ++i) { if (nb1 + i < region) dir_part[region_base + nb1 + i] = (uint16_t)(2 * t + 1); else *err = 1u; }   // unless it ends up the last one
         const uint32_t entries = all & 0xFFFFu;
-        next_chunk += all >> 16;
-        __syncthreads();                                         // loc_off and the chunk bases are complete
+        // Chunk ids are handed out contiguously, so "every fresh chunk of this tile lies inside the region" is one uniform test.
+        // A tile that fails it is dropped as a whole AND `err` is raised: the call fails with AIX_ERR_UNSUPPORTED, never short counts.
+        const bool fits = next_chunk + (all >> 16) <= region;
+        if (!fits && t == 0) *err = 1u;
+        const uint32_t excl = off + s - mine;
+        const uint32_t e0 = excl & 0xFFFFu, e1 = e0 + a, nb0 = next_chunk + (excl >> 16), nb1 = nb0 + k0;
+        // where the entries of a partition go, as two deltas to their index i inside the sorted tile: i < T lands in the current
+        // chunk at A + i, the rest in the fresh chunks (consecutive ids) at B + i
+        loc_t[2 * t] = e0 | ((e0 + C13_CH - f0) << 16);          // T <= 32768 + 256
+        loc_t[2 * t + 1] = e1 | ((e1 + C13_CH - f1) << 16);
+        hist[2 * t] = (cur0 >> C13_FILLBITS) * C13_CH + f0 - e0;
+        hist[2 * t + 1] = (cur1 >> C13_FILLBITS) * C13_CH + f1 - e1;
+        delta_b[2 * t] = nb0 * C13_CH + f0 - e0 - C13_CH;
+        delta_b[2 * t + 1] = nb1 * C13_CH + f1 - e1 - C13_CH;
+        if (fits) {
+            for (uint32_t i = 0; i < k0; ++i) dir_part[region_base + nb0 + i] = (uint16_t)(2 * t);        // fill stays at the pre-set 256
+            for (uint32_t i = 0; i < k1; ++i) dir_part[region_base + nb1 + i] = (uint16_t)(2 * t + 1);    // unless it ends up the last one
+            cur0 = k0 ? ((nb0 + k0 - 1) << C13_FILLBITS) | (tot0 - k0 * C13_CH) : (cur0 & ~FILLMASK) | tot0;
+            cur1 = k1 ? ((nb1 + k1 - 1) << C13_FILLBITS) | (tot1 - k1 * C13_CH) : (cur1 & ~FILLMASK) | tot1;
+            next_chunk += all >> 16;
+        }
+        __syncthreads();                                         // the per-partition words are complete
         for_each_window13<0>(run, [&](int j, uint32_t code, uint32_t ok) {
             if (ok) {
                 const uint32_t p = code >> C13_BINBITS;
                 const uint32_t r = (j & 1) ? (rank[j >> 1] >> 16) : (rank[j >> 1] & 0xFFFFu);
-                sorted[loc_off[p] + r] = (p << 16) | (code & (C13_BINS - 1));
+                sorted[(loc_t[p] & 0xFFFFu) + r] = (p << 16) | (code & (C13_BINS - 1));
             }
         });
         __syncthreads();
-        for (uint32_t i = t; i < entries; i += C13_TB) {
-            const uint32_t e = sorted[i];
-            const uint32_t p = e >> 16;
-            const uint32_t c = cursor[p];
-            const uint32_t pos = (c & FILLMASK) + (i - loc_off[p]);
-            uint32_t chunk, o;
-            if (pos < (uint32_t)C13_CH) { chunk = c >> C13_FILLBITS; o = pos; }
-            else { chunk = hist[p] + (pos - C13_CH) / C13_CH; o = (pos - C13_CH) % C13_CH; }
-            if (chunk < region) parts[(uint64_t)(region_base + chunk) * C13_CH + o] = (uint16_t)e; else *err = 1u;
+        if constexpr (PREFETCH) { if (tile + gridDim.x < ntiles) raw = src.fetch(tile + gridDim.x, t); }      // in flight while this tile is written out
+        if (fits) {
+            uint16_t* const out = parts + (uint64_t)region_base * C13_CH;
+            for (uint32_t i = t; i < entries; i += C13_TB) {
+                const uint32_t e = sorted[i];
+                const uint32_t p = e >> 16;
+                const uint32_t d = i < (loc_t[p] >> 16) ? hist[p] : delta_b[p];
+                out[d + i] = (uint16_t)e;
+            }
         }
         __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {                            // advance the two cursors this lane owns (recomputed: nothing but a, b stayed live)
-            const uint32_t p = 2 * t + q, c = cursor[p], tot = (c & FILLMASK) + (q ? b : a);
-            if (tot > (uint32_t)C13_CH) {
-                const uint32_t k = (tot - 1) / C13_CH;
-                cursor[p] = ((hist[p] + k - 1) << C13_FILLBITS) | (tot - k * C13_CH);
-            } else {
-                cursor[p] = (c & ~FILLMASK) | tot;
-            }
-            hist[p] = 0;
-        }
+        hist[2 * t] = 0;
+        hist[2 * t + 1] = 0;
         if (t < C13_DUMMY) hist[C13_P + t] = 0;
         __syncthreads();
     }
     // the chunk each (workgroup, partition) pair was still filling is the only one that is not full
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const uint32_t c = cursor[2 * t + q], fill = c & FILLMASK, chunk = c >> C13_FILLBITS;
-        if (fill < (uint32_t)C13_CH) { if (chunk < region) dir_cnt[region_base + chunk] = (uint16_t)fill; else *err = 1u; }
+    {
+        const uint32_t fl0 = cur0 & FILLMASK, fl1 = cur1 & FILLMASK;
+        if (fl0 < (uint32_t)C13_CH) dir_cnt[region_base + (cur0 >> C13_FILLBITS)] = (uint16_t)fl0;
+        if (fl1 < (uint32_t)C13_CH) dir_cnt[region_base + (cur1 >> C13_FILLBITS)] = (uint16_t)fl1;
     }
 }
 
@@ -366,13 +385,20 @@ static hipError_t partitioned_histogram(const SRC& src, uint64_t nwin, void* wor
     {   // > 64 KiB of dynamic LDS needs the attribute; set per call (cheap, and correct for every device / thread)
         hipError_t e = hipFuncSetAttribute((const void*)k_c13_hist_chunked, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)k_c13_split_chunked<SRC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)split_lds);
+        e = hipFuncSetAttribute((const void*)k_c13_split_chunked<SRC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)split_lds);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)k_c13_split_chunked<SRC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)split_lds);
         if (e != hipSuccess) return e;
     }
     hipError_t e = hipMemsetD16Async((hipDeviceptr_t)dir_part, (unsigned short)C13_P, cap, s);     // "no partition": sorts behind every real one
     if (e == hipSuccess) e = hipMemsetD16Async((hipDeviceptr_t)dir_cnt, (unsigned short)C13_CH, cap, s);     // chunks are full unless the split says otherwise
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_c13_split_chunked<SRC>, dim3(grid), dim3(C13_TB), split_lds, s, src, ntiles, chunk_region(nwin), dir_part, dir_cnt, parts, err);
+    // the next tile's loads in flight during the write-out: measured SLOWER for the 13-mer source (3.45 against 3.10 ms per 10 M reads: eleven more
+    // live registers put the kernel at its 128-VGPR limit), so it is off unless asked for (A/B switch); the slot source has nothing to fetch ahead
+    bool prefetch = false;
+    if (const char* pf = getenv("AIX_C13_PREFETCH")) prefetch = atoi(pf) != 0;
+    if (prefetch) hipLaunchKernelGGL((k_c13_split_chunked<SRC, true>), dim3(grid), dim3(C13_TB), split_lds, s, src, ntiles, chunk_region(nwin), dir_part, dir_cnt, parts, err);
+    else hipLaunchKernelGGL((k_c13_split_chunked<SRC, false>), dim3(grid), dim3(C13_TB), split_lds, s, src, ntiles, chunk_region(nwin), dir_part, dir_cnt, parts, err);
     auto vals = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), ChunkDesc{dir_cnt});
     e = rocprim::radix_sort_pairs(tmp, tmp_bytes, (const uint16_t*)dir_part, spart, vals, sdesc, (size_t)cap, 0u, 12u, s);
     if (e != hipSuccess) return e;

@@ -975,10 +975,13 @@ def main():
                 except OSError:
                     pass
         windows = int(reads_t.numel() - 22)
-        # bytes the fill asks for: 23+4 per window (probe: query bytes in, bucket out), 3 x 16 + 16 per probed window, and the
-        # radix sort of (bucket, offset) pairs (4 passes x 16 B read + written), 8 B per placed offset
+        # bytes the fill asks for, per window: 1 in + 4 out (probe: read byte in, bucket out) + the probe's line; then the grouping of the
+        # (bucket, offset) pairs: MSD path = 4 in + 8 out (level 1), 8 in (level-2 count), 8 in + 8 out (level-2 scatter), 8 in (final);
+        # sort path = 4 radix passes x 16 B read + written; and 8 B per placed offset
         pp = ix.probe_profile()
-        achieved = (windows * (1.0 + 4.0 + pp["bytes_per_hit_probe"] + 4 * 16.0) + 8.0 * int(indices[-1])) / (kern_ms * 1e-3) / 1e9
+        msd = os.environ.get("AIX_A2_MSD", "1") != "0" and windows >= (1 << 22)
+        grouping_bytes = 44.0 if msd else 4 * 16.0
+        achieved = (windows * (1.0 + 4.0 + pp["bytes_per_hit_probe"] + grouping_bytes) + 8.0 * int(indices[-1])) / (kern_ms * 1e-3) / 1e9
         out.update({**({"cpu_baseline": cbp} if cbp else {}),
                     "metric": "reads_per_sec_positions_fill_23mer", "value": world * a.reads * a.steps / wall, "unit": "reads/s",
                     "ms_per_step": wall / a.steps * 1e3, "dtype": "u64",
@@ -986,7 +989,9 @@ def main():
                                "reads": a.reads, "windows": windows, "positions_total": int(indices[-1]), "filled": int((pos != 0).sum()),
                                "host_buffer_call_ms": host_dt * 1e3, "host_buffer_reads_per_s": a.reads / host_dt},
                     "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                                 "kernel": "k_a2_probe + rocprim radix_sort_pairs + k_a2_first/k_a2_place",
+                                 "kernel": ("k_a2_probe + k_k1_split<A2Keys> + k_k1_count + k_k1_scatter<u64> + k_a2_final (two-level MSD partition + per-bucket LDS stage)"
+                                            if msd else "k_a2_probe + rocprim radix_sort_pairs + k_a2_first/k_a2_place"),
+                                 "grouping": "msd" if msd else "radix sort", "requested_bytes_per_window": 1.0 + 4.0 + pp["bytes_per_hit_probe"] + grouping_bytes,
                                  "kernel_ms": kern_ms, "reads_per_launch": a.reads, "windows_per_launch": windows, "probe": pp["name"],
                                  "calls_in_process": a.steps + a.warmup + 1 + (1 if cbp else 0)}})
         tr = load_pmc_traffic("positions23", reads_per_launch=a.reads)
