@@ -59,9 +59,9 @@ __global__ void __launch_bounds__(A2_FB) k_a2_final(const IndexDev ix, const uin
                                                    const uint64_t* __restrict__ indices, uint64_t* __restrict__ positions, A2Over* __restrict__ over,
                                                    uint32_t* __restrict__ over_b, uint64_t* __restrict__ over_off) {
     __shared__ uint32_t hist2[2][A2_R];               // pairs per slot of the bucket; two copies: the one of the NEXT bucket is cleared while this one is read
-    __shared__ uint32_t cursor[A2_R];                 // exclusive scan of hist; after the grouping pass: the END of every slot's run
-    __shared__ uint32_t binlim[A2_R];                 // slots still free in the slot's positions range: tf[h] - filled[h]
-    __shared__ uint64_t binbase[A2_R];                // indices[h] + filled[h]
+    __shared__ uint32_t cursor[A2_R];                 // exclusive scan of the padded counts: where every slot's run starts (a bucket of more than 1024 pairs advances it while grouping)
+    __shared__ uint4 slotrec[A2_R];                   // per slot, one 16-byte read: x = start of its run in offs | pairs << 16, y = slots still free in its
+                                                      // positions range (tf[h] - filled[h]), z:w = indices[h] + filled[h]
     __shared__ __attribute__((aligned(16))) uint32_t offs[A2_CAP + 4];      // window offsets grouped by slot
     __shared__ uint32_t wsum[A2_FB / 64];
     __shared__ uint32_t heavy_n[2];                   // slots of the bucket with more than A2_HEAVY pairs (cleared with hist2)
@@ -120,9 +120,10 @@ __global__ void __launch_bounds__(A2_FB) k_a2_final(const IndexDev ix, const uin
         }
         uint32_t* hist = hist2[par];
         // the usual bucket (<= 1024 pairs) lives in registers; the tail of a fuller one is re-read (it is in L2: level 2 has just written it)
+        uint32_t r[A2_PRE];                                        // arrival number of a pair among the pairs of its slot: its place inside the slot's run
 #pragma unroll
         for (int q = 0; q < A2_PRE; ++q)
-            if (e[q] != ~0ull) atomicAdd(&hist[(uint32_t)(e[q] >> 32)], 1u);
+            if (e[q] != ~0ull) r[q] = atomicAdd(&hist[(uint32_t)(e[q] >> 32)], 1u);
         for (uint32_t i = t + A2_PRE * A2_FB; i < n_e; i += A2_FB) atomicAdd(&hist[(uint32_t)(rem[lo + i] >> 32)], 1u);
         __syncthreads();                                           // also: every wave has left the previous bucket
         // scan: a lane owns SPT consecutive slots and publishes their output ranges. Every slot's run starts at a multiple of four
@@ -162,33 +163,42 @@ __global__ void __launch_bounds__(A2_FB) k_a2_final(const IndexDev ix, const uin
                     const uint32_t c = c4[j], cr = (c + 3u) & ~3u;
                     for (uint32_t i = c; i < cr; ++i) offs[off + i] = 0xFFFFFFFFu;
                     uint32_t lim = 0;
+                    uint64_t base = 0;
                     if (c && h < n) {
                         const uint32_t fl = s_fl[j];
-                        binbase[s] = s_ind[j] + fl;
+                        base = s_ind[j] + fl;
                         const uint64_t room = s_tf[j] > fl ? s_tf[j] - fl : 0ull;
                         lim = room > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)room;
                         if (advance) { const uint64_t tot = (uint64_t)fl + c; filled[h] = tot > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)tot; }
                         if (c > (uint32_t)A2_HEAVY) heavy_s[par][atomicAdd(&heavy_n[par], 1u)] = s;
                     }
-                    binlim[s] = lim;
+                    slotrec[s] = make_uint4(off | (c << 16), lim, (uint32_t)base, (uint32_t)(base >> 32));
                     off += cr;
                 }
             }
         }
         __syncthreads();
         // grouping: any order inside a slot's run (the order is recovered from the offsets below)
+        if (n_e <= (uint32_t)(A2_PRE * A2_FB)) {                   // the usual bucket: every pair kept its arrival number, no second atomic
 #pragma unroll
-        for (int q = 0; q < A2_PRE; ++q)
-            if (e[q] != ~0ull) offs[atomicAdd(&cursor[(uint32_t)(e[q] >> 32)], 1u)] = (uint32_t)e[q];
-        for (uint32_t i = t + A2_PRE * A2_FB; i < n_e; i += A2_FB) { const uint64_t x = rem[lo + i]; offs[atomicAdd(&cursor[(uint32_t)(x >> 32)], 1u)] = (uint32_t)x; }
+            for (int q = 0; q < A2_PRE; ++q)
+                if (e[q] != ~0ull) offs[cursor[(uint32_t)(e[q] >> 32)] + r[q]] = (uint32_t)e[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < A2_PRE; ++q)
+                if (e[q] != ~0ull) offs[atomicAdd(&cursor[(uint32_t)(e[q] >> 32)], 1u)] = (uint32_t)e[q];
+            for (uint32_t i = t + A2_PRE * A2_FB; i < n_e; i += A2_FB) { const uint64_t x = rem[lo + i]; offs[atomicAdd(&cursor[(uint32_t)(x >> 32)], 1u)] = (uint32_t)x; }
+        }
         __syncthreads();
         // a slot with many pairs (a k-mer repeated hundreds of times inside this piece): its run is sorted in place by the whole
         // workgroup — a bitonic network whose compare-exchanges all point upwards, so that runs of any length need no padding
         // (a partner index past the run is a virtual +infinity that would never move) — and placed straight from the sorted run
         const uint32_t nheavy = heavy_n[par];                      // uniform
         for (uint32_t hi = 0; hi < nheavy; ++hi) {
-            const uint32_t s = heavy_s[par][hi], cnt = hist[s];
-            uint32_t* run = offs + (cursor[s] - cnt);
+            const uint32_t s = heavy_s[par][hi];
+            const uint4 rec = slotrec[s];
+            const uint32_t cnt = rec.x >> 16;
+            uint32_t* run = offs + (rec.x & 0xFFFFu);
             uint32_t half_p = 1;
             while (2 * half_p < cnt) half_p <<= 1;                 // pairs per step = P / 2, P = the power of two >= cnt
             auto cmpx = [&](uint32_t i, uint32_t x) {
@@ -209,21 +219,22 @@ __global__ void __launch_bounds__(A2_FB) k_a2_final(const IndexDev ix, const uin
                     __syncthreads();
                 }
             }
-            const uint32_t lim = min(cnt, binlim[s]);
-            const uint64_t base = binbase[s];
+            const uint32_t lim = min(cnt, rec.y);
+            const uint64_t base = ((uint64_t)rec.w << 32) | rec.z;
             for (uint32_t i = t; i < lim; i += A2_FB) positions[base + i] = piece_first + run[i] + 1;
         }
         // every other pair ranks itself among the offsets of its slot (four per LDS read): ascending offsets = the reference's arrival order
         auto place = [&](uint64_t x) {
             const uint32_t s = (uint32_t)(x >> 32), off = (uint32_t)x;
-            const uint32_t cnt = hist[s], end = cursor[s], first = end - cnt;
+            const uint4 rec = slotrec[s];
+            const uint32_t cnt = rec.x >> 16, first = rec.x & 0xFFFFu, end = first + cnt;
             if (cnt > (uint32_t)A2_HEAVY) return;                                                  // placed above
             uint32_t rank = 0;
             for (uint32_t q = first; q < end; q += 4) {                                            // `first` is a multiple of four, the run is padded with +infinity
                 const uint4 v = *reinterpret_cast<const uint4*>(&offs[q]);
                 rank += (v.x < off ? 1u : 0u) + (v.y < off ? 1u : 0u) + (v.z < off ? 1u : 0u) + (v.w < off ? 1u : 0u);
             }
-            if (rank < binlim[s]) positions[binbase[s] + rank] = piece_first + off + 1;          // hash.cpp:1037-1040, 1-based
+            if (rank < rec.y) positions[(((uint64_t)rec.w << 32) | rec.z) + rank] = piece_first + off + 1;      // hash.cpp:1037-1040, 1-based
         };
 #pragma unroll
         for (int q = 0; q < A2_PRE; ++q)
