@@ -26,7 +26,7 @@ static constexpr int A2_FB = 256;                     // threads of the per-buck
 static constexpr int A2_CAP = 4096;                   // pairs a bucket may hold in LDS
 static constexpr int A2_PRE = 4;                      // pairs per lane held in registers (256 x 4 = 1024: the usual bucket)
 static constexpr int A2_HEAVY = 128;                   // pairs of one slot above which its run is sorted cooperatively instead of ranked pair by pair
-static constexpr int A2_RBITS_MAX = 9;
+static constexpr int A2_RBITS_MAX = 8;
 static constexpr int A2_R = 1 << A2_RBITS_MAX;        // slots per bucket at most
 
 // level-1 source: the probe's output, keys[i] = bucket of window i (>= nslots: none)
@@ -63,6 +63,7 @@ __global__ void __launch_bounds__(A2_FB) k_a2_final(const IndexDev ix, const uin
     __shared__ uint4 slotrec[A2_R];                   // per slot, one 16-byte read: x = start of its run in offs | pairs << 16, y = slots still free in its
                                                       // positions range (tf[h] - filled[h]), z:w = indices[h] + filled[h]
     __shared__ __attribute__((aligned(16))) uint32_t offs[A2_CAP + 4];      // window offsets grouped by slot
+    __shared__ uint16_t grp2slot[A2_CAP / 4 + 2];     // slot of every aligned group of four entries of offs (a run starts at a multiple of four); 0xFFFF: placed by the heavy path
     __shared__ uint32_t wsum[A2_FB / 64];
     __shared__ uint32_t heavy_n[2];                   // slots of the bucket with more than A2_HEAVY pairs (cleared with hist2)
     __shared__ uint32_t heavy_s[2][A2_CAP / A2_HEAVY];
@@ -173,6 +174,7 @@ __global__ void __launch_bounds__(A2_FB) k_a2_final(const IndexDev ix, const uin
                         if (c > (uint32_t)A2_HEAVY) heavy_s[par][atomicAdd(&heavy_n[par], 1u)] = s;
                     }
                     slotrec[s] = make_uint4(off | (c << 16), lim, (uint32_t)base, (uint32_t)(base >> 32));
+                    if (c <= (uint32_t)A2_HEAVY) for (uint32_t g = off >> 2; g < ((off + cr) >> 2); ++g) grp2slot[g] = (uint16_t)s;
                     off += cr;
                 }
             }
@@ -199,6 +201,7 @@ __global__ void __launch_bounds__(A2_FB) k_a2_final(const IndexDev ix, const uin
             const uint4 rec = slotrec[s];
             const uint32_t cnt = rec.x >> 16;
             uint32_t* run = offs + (rec.x & 0xFFFFu);
+            for (uint32_t g = t; g < ((cnt + 3u) >> 2); g += A2_FB) grp2slot[((rec.x & 0xFFFFu) >> 2) + g] = 0xFFFFu;      // visible after the first barrier below
             uint32_t half_p = 1;
             while (2 * half_p < cnt) half_p <<= 1;                 // pairs per step = P / 2, P = the power of two >= cnt
             auto cmpx = [&](uint32_t i, uint32_t x) {
@@ -223,23 +226,22 @@ __global__ void __launch_bounds__(A2_FB) k_a2_final(const IndexDev ix, const uin
             const uint64_t base = ((uint64_t)rec.w << 32) | rec.z;
             for (uint32_t i = t; i < lim; i += A2_FB) positions[base + i] = piece_first + run[i] + 1;
         }
-        // every other pair ranks itself among the offsets of its slot (four per LDS read): ascending offsets = the reference's arrival order
-        auto place = [&](uint64_t x) {
-            const uint32_t s = (uint32_t)(x >> 32), off = (uint32_t)x;
+        // every other pair ranks itself among the offsets of its slot, four per LDS read (ascending offsets = the reference's arrival
+        // order). The lanes walk the GROUPED array: neighbouring lanes hold pairs of the same slot, so the slot record and the run are
+        // read at a handful of distinct addresses per wave instruction (broadcasts) instead of 64 scattered ones
+        for (uint32_t i = t; i < padded; i += A2_FB) {
+            const uint32_t off = offs[i];
+            const uint32_t s = grp2slot[i >> 2];
+            if (off == 0xFFFFFFFFu || s == 0xFFFFu) continue;                                      // padding / placed by the heavy path
             const uint4 rec = slotrec[s];
             const uint32_t cnt = rec.x >> 16, first = rec.x & 0xFFFFu, end = first + cnt;
-            if (cnt > (uint32_t)A2_HEAVY) return;                                                  // placed above
             uint32_t rank = 0;
             for (uint32_t q = first; q < end; q += 4) {                                            // `first` is a multiple of four, the run is padded with +infinity
                 const uint4 v = *reinterpret_cast<const uint4*>(&offs[q]);
                 rank += (v.x < off ? 1u : 0u) + (v.y < off ? 1u : 0u) + (v.z < off ? 1u : 0u) + (v.w < off ? 1u : 0u);
             }
             if (rank < rec.y) positions[(((uint64_t)rec.w << 32) | rec.z) + rank] = piece_first + off + 1;      // hash.cpp:1037-1040, 1-based
-        };
-#pragma unroll
-        for (int q = 0; q < A2_PRE; ++q)
-            if (e[q] != ~0ull) place(e[q]);
-        for (uint32_t i = t + A2_PRE * A2_FB; i < n_e; i += A2_FB) place(rem[lo + i]);
+        }
         par ^= 1;
     }
 }
@@ -291,8 +293,8 @@ static inline uint64_t up256(uint64_t x) { return (x + 255) / 256 * 256; }
 static inline unsigned grid256(uint64_t work) { return (unsigned)std::min<uint64_t>(std::max<uint64_t>((work + 255) / 256, 1), 8192); }
 
 bool a2_msd_eligible(uint64_t nwin, uint64_t n) {
-    if (const char* e = getenv("AIX_A2_MSD")) return atoi(e) != 0 && nwin > 0 && nwin <= (1ull << 31) && n > 0 && n <= (1ull << 31);      // A/B and test switch
-    return nwin >= (1ull << 22) && nwin <= (1ull << 31) && n > 0 && n <= (1ull << 31);                                                    // short buffers: fewer launches win
+    if (const char* e = getenv("AIX_A2_MSD")) return atoi(e) != 0 && nwin > 0 && nwin <= (1ull << 31) && n > 0 && n <= (1ull << 30);      // A/B and test switch
+    return nwin >= (1ull << 22) && nwin <= (1ull << 31) && n > 0 && n <= (1ull << 30);                                                    // short buffers: fewer launches win
 }
 
 // keys: the probe's output for the nwin windows of this piece (bucket, or >= n for none). filled: u32[n] occurrences of every

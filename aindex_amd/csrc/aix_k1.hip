@@ -117,9 +117,9 @@ __global__ void __launch_bounds__(K1_FB) k_k1_final(const uint32_t* __restrict__
                                                    uint32_t* __restrict__ overflow) {
     __shared__ uint32_t hk[K1_CAP];          // remainder + 1 (0 = empty)
     __shared__ uint32_t hc[K1_CAP];
-    __shared__ uint32_t dk[K1_DMAX];
+    __shared__ __attribute__((aligned(16))) uint32_t dk[K1_DMAX + 4];      // + the +infinity padding of the rank pass
     __shared__ uint32_t dc[K1_DMAX];
-    __shared__ uint32_t ndist, m_out;
+    __shared__ uint32_t m_out;
     const uint32_t t = threadIdx.x;
     // A bucket is ~10^3 entries: its global loads (two bases, then the entries) are a dependent chain of HBM latencies that
     // would dominate the few microseconds of LDS work. The base pair and the first 1024 entries of the NEXT bucket are therefore
@@ -135,6 +135,10 @@ __global__ void __launch_bounds__(K1_FB) k_k1_final(const uint32_t* __restrict__
         }
     };
     prefetch(blockIdx.x);
+    // invariant at the top of every bucket: dk[] holds +infinity everywhere, so the rank pass can read whole 16-byte vectors past the
+    // last distinct key; the entries a bucket has used are reset when the next one begins (every wave has passed the closing barrier)
+    for (uint32_t i = t; i < (uint32_t)K1_DMAX + 4u; i += K1_FB) dk[i] = 0xFFFFFFFFu;
+    uint32_t used = 0;                                          // entries of dk the previous bucket wrote (uniform)
     for (uint32_t b = blockIdx.x; b < nbuckets; b += gridDim.x) {
         const uint32_t lo = nlo, n_e = nn;
         uint32_t cur[K1_PRE];
@@ -147,7 +151,9 @@ __global__ void __launch_bounds__(K1_FB) k_k1_final(const uint32_t* __restrict__
         const uint32_t want = 2u * min(n_e, (uint32_t)K1_DMAX);
         while (cap < want && cap < (uint32_t)K1_CAP) cap <<= 1;
         for (uint32_t i = t; i < cap; i += K1_FB) { hk[i] = 0; hc[i] = 0; }
-        if (t == 0) { ndist = 0; m_out = 0; }
+        for (uint32_t i = t; i < used; i += K1_FB) dk[i] = 0xFFFFFFFFu;
+        used = 0;
+        if (t == 0) m_out = 0;
         __syncthreads();
         auto insert = [&](uint32_t v) {
             const uint32_t key = v + 1u;                         // remainders are < 2^31 (s2 <= 31): + 1 cannot wrap to the empty marker
@@ -155,7 +161,6 @@ __global__ void __launch_bounds__(K1_FB) k_k1_final(const uint32_t* __restrict__
             for (uint32_t probes = 0; probes < cap; ++probes) {
                 h &= cap - 1;
                 const uint32_t old = atomicCAS(&hk[h], 0u, key);
-                if (old == 0u) atomicAdd(&ndist, 1u);
                 if (old == 0u || old == key) { atomicAdd(&hc[h], 1u); break; }
                 ++h;
             }
@@ -164,18 +169,27 @@ __global__ void __launch_bounds__(K1_FB) k_k1_final(const uint32_t* __restrict__
         for (int q = 0; q < K1_PRE; ++q) if (t + q * K1_FB < n_e) insert(cur[q]);
         for (uint32_t i = t + K1_PRE * K1_FB; i < n_e; i += K1_FB) insert(in32[lo + i]);      // the tail of an oversized bucket
         __syncthreads();
-        const uint32_t nd = ndist;
-        if (nd > (uint32_t)K1_DMAX) {                            // too many distinct remainders for the LDS arrays (or a full table dropped some)
+        // compaction of the occupied slots: one LDS atomic per WAVE (ballot + prefix popcount), not one per distinct key on one address
+        for (uint32_t i0 = 0; i0 < cap; i0 += K1_FB) {
+            const uint32_t i = i0 + t;
+            const uint32_t k = i < cap ? hk[i] : 0u;
+            const uint64_t mask = __ballot(k != 0u);
+            uint32_t base = 0;
+            if ((t & 63u) == 0u && mask) base = atomicAdd(&m_out, (uint32_t)__popcll(mask));
+            base = __shfl(base, 0);
+            if (k) {
+                const uint32_t idx = base + (uint32_t)__popcll(mask & ((1ull << (t & 63u)) - 1ull));
+                if (idx < (uint32_t)K1_DMAX) { dk[idx] = k - 1u; dc[idx] = hc[i]; }
+            }
+        }
+        __syncthreads();
+        const uint32_t m = m_out;
+        used = min(m, (uint32_t)K1_DMAX);
+        if (m > (uint32_t)K1_DMAX) {                             // too many distinct remainders for the LDS arrays (or a full table dropped some)
             if (t == 0) { *overflow = 1u; distinct_m[b] = 0; }
             __syncthreads();
             continue;
         }
-        for (uint32_t i = t; i < cap; i += K1_FB) {
-            const uint32_t k = hk[i];
-            if (k) { const uint32_t idx = atomicAdd(&m_out, 1u); dk[idx] = k - 1u; dc[idx] = hc[i]; }
-        }
-        __syncthreads();
-        const uint32_t m = m_out;
         const uint64_t prefix = (uint64_t)b << s2;               // bucket id = the top 11 + D2 bits of the code
         if (m <= 384u) {
             // few distinct keys (the usual case: a bucket's ~10^3 entries are ~10^2 distinct k-mers at sequencing depth): every lane
@@ -184,27 +198,36 @@ __global__ void __launch_bounds__(K1_FB) k_k1_final(const uint32_t* __restrict__
             for (uint32_t i = t; i < m; i += K1_FB) {
                 const uint32_t key = dk[i];
                 uint32_t r = 0;
-                for (uint32_t j = 0; j < m; ++j) r += dk[j] < key ? 1u : 0u;
+                for (uint32_t j = 0; j < m; j += 4) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(&dk[j]);
+                    r += (v.x < key ? 1u : 0u) + (v.y < key ? 1u : 0u) + (v.z < key ? 1u : 0u) + (v.w < key ? 1u : 0u);
+                }
                 keys_out[lo + r] = prefix | key;
                 cnt_out[lo + r] = dc[i];
             }
         } else {
-            uint32_t mp = 1;
-            while (mp < m) mp <<= 1;
-            for (uint32_t i = m + t; i < mp; i += K1_FB) { dk[i] = 0xFFFFFFFFu; dc[i] = 0; }
-            __syncthreads();
-            for (uint32_t k = 2; k <= mp; k <<= 1) {             // bitonic sort of (dk, dc) by dk, ascending
-                for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                    for (uint32_t i = t; i < mp; i += K1_FB) {
-                        const uint32_t x = i ^ j;
-                        if (x > i) {
-                            const uint32_t ka = dk[i], kb = dk[x];
-                            const bool up = (i & k) == 0;
-                            if ((ka > kb) == up) {
-                                dk[i] = kb; dk[x] = ka;
-                                const uint32_t ca = dc[i]; dc[i] = dc[x]; dc[x] = ca;
-                            }
-                        }
+            // many distinct keys: bitonic sort of (dk, dc) by dk inside LDS. Every compare-exchange points upwards (the first step of a
+            // merge pairs mirror positions), so m needs no rounding up to a power of two: a partner index at or past m is a virtual
+            // +infinity that would never move — nothing is read or written past the m entries
+            uint32_t half_p = 1;
+            while (2 * half_p < m) half_p <<= 1;                 // pairs per step = P / 2, P = the power of two >= m
+            auto cmpx = [&](uint32_t a, uint32_t x) {
+                if (x < m) {
+                    const uint32_t ka = dk[a], kb = dk[x];
+                    if (ka > kb) { dk[a] = kb; dk[x] = ka; const uint32_t ca = dc[a]; dc[a] = dc[x]; dc[x] = ca; }
+                }
+            };
+            for (uint32_t k = 2; k <= 2 * half_p; k <<= 1) {
+                const uint32_t hk2 = k >> 1;
+                for (uint32_t p = t; p < half_p; p += K1_FB) {
+                    const uint32_t blk = p / hk2 * k, pos = p & (hk2 - 1);
+                    cmpx(blk + pos, blk + k - 1 - pos);
+                }
+                __syncthreads();
+                for (uint32_t j = k >> 2; j > 0; j >>= 1) {
+                    for (uint32_t p = t; p < half_p; p += K1_FB) {
+                        const uint32_t a = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                        cmpx(a, a + j);
                     }
                     __syncthreads();
                 }

@@ -1369,7 +1369,12 @@ def test_kmer_counter_msd_path_equals_radix_path_and_oracle(monkeypatch):
     polya = (b"A" * 150 + b"\n") * 3000 + (b"ACGT" * 37 + b"AC\n") * 500 + reads[:200_000]
     prefix = b"AAAAAAAAAA"
     narrow = b"".join(prefix + bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 13)) + b"\n" for _ in range(60_000))
-    cases = [(reads, 23, 2, 1), (reads, 23, 1, 2), (reads, 13, 2, 1), (polya, 23, 1, 1), (polya, 23, 2, 3), (narrow, 23, 0, 1), (narrow, 13, 0, 1), (b"", 23, 1, 1),
+    # buckets of 500 .. 1 530 distinct keys (the in-LDS bitonic sort of a bucket, also past 1 024 keys; 1 536 is the most a bucket may
+    # hold): 8-base prefixes pin the bucket (11 + 4 bits at this size), the rest is random
+    pre8 = ["ACGTACGT", "CCGTTAGA", "GATTACAC", "TTGACCAG", "AGAGAGAT", "CTCTGGAA"]
+    dense = b"".join(pre8[j].encode() + bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 15)) + b"\n"
+                     for j, m in enumerate((500, 800, 1100, 1300, 1450, 1530)) for _ in range(m))
+    cases = [(reads, 23, 2, 1), (reads, 23, 1, 2), (reads, 13, 2, 1), (polya, 23, 1, 1), (polya, 23, 2, 3), (narrow, 23, 0, 1), (narrow, 13, 0, 1), (dense, 23, 0, 1), (b"", 23, 1, 1),
              (b"ACGTACGTACGTACGTACGTACG\n", 23, 1, 1)]
     for buf, k, mode, minc in cases:
         monkeypatch.delenv("AIX_K1_ROCPRIM", raising=False)
