@@ -73,6 +73,7 @@ struct aix_index {
     BkEntry* bk = nullptr;                     // verification table: nb buckets of eight {code, tf, slot} entries (one 128-byte line each)
     uint32_t nb = 0;
     uint32_t bk_lpp = 8;                       // lanes that share one bucket read
+    bool bk_lpp_set = false;                   // chosen by the caller (AIX_BUCKET_LANES / aix_index_set_bucket_table): then every consumer uses it
     uint64_t bk_unfiled = 0;                   // keys beyond the eighth of their bucket (answered through the MPHF)
     bool bk_enabled = true;
     BkEntry* mk = nullptr;                     // minimizer-keyed copy of the table for the streaming counter (nbm buckets of 16 entries)
@@ -285,7 +286,7 @@ static int build_bucket_table(aix_index* h, hipStream_t s) {
     if (const char* e = getenv("AIX_BUCKET_TABLE")) { if (atoi(e) == 0) return AIX_OK; }
     double load = 4.0;
     if (const char* e = getenv("AIX_BUCKET_LOAD")) { const double v = atof(e); if (v >= 0.25 && v <= 8.0) load = v; }
-    if (const char* e = getenv("AIX_BUCKET_LANES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) h->bk_lpp = (uint32_t)v; }
+    if (const char* e = getenv("AIX_BUCKET_LANES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) { h->bk_lpp = (uint32_t)v; h->bk_lpp_set = true; } }
     uint64_t nb = (uint64_t)((double)h->n / load) + 1;
     if (nb > 0xFFFFFFF0ull) nb = 0xFFFFFFF0ull;
     const uint64_t bytes = nb * 8 * sizeof(BkEntry);
@@ -622,7 +623,7 @@ extern "C" int aix_index_set_bucket_table(aix_index_t* h, int enabled, int lanes
     if (!h) return AIX_ERR_ARG;
     if (lanes != 0 && lanes != 1 && lanes != 2 && lanes != 4 && lanes != 8) return AIX_ERR_ARG;
     h->bk_enabled = enabled != 0;
-    if (lanes) h->bk_lpp = (uint32_t)lanes;
+    if (lanes) { h->bk_lpp = (uint32_t)lanes; h->bk_lpp_set = true; }
     return AIX_OK;
 }
 
@@ -864,7 +865,13 @@ extern "C" int aix_count23_fixed_dev(aix_index_t* h, const char* d_plain, uint64
             HIPCHK(hipMemsetAsync((uint32_t*)h->work13 + 1, 0, 4, s));
             HIPCHK(launch_stream23_slots(d, (const uint8_t*)d_plain + first, w + 22, canon_mode, slots, (uint32_t*)h->work13 + 1, s));
         }
-        else HIPCHK(launch_probe23_slots(d, (const uint8_t*)d_plain + first, w + 22, canon_mode, slots, s));
+        else {
+            // the slot-stream probe of the counter runs best with two lanes per bucket line (38.7-40.4 against 42.5-42.7 ms per 10 M reads with
+            // eight, same box): nothing but the 4-byte slot leaves the kernel, so fewer, wider reads per probe win; lookups keep eight
+            IndexDev dc = d;
+            if (!h->bk_lpp_set) dc.bk_lpp = 2;
+            HIPCHK(launch_probe23_slots(dc, (const uint8_t*)d_plain + first, w + 22, canon_mode, slots, s));
+        }
         HIPCHK(launch_histogram_slots(slots, w, h->work13, d_tf_out, h->n, s));
     }
     uint32_t dropped = 0;

@@ -225,6 +225,15 @@ def count_distinct_sharded(plain: bytes, k: int, canon_mode: int = 2, min_count:
     return exchange_merge_counts(keys, counts, min_count)
 
 
+def count_distinct_sharded_t(plain_t, k: int, canon_mode: int = 2, min_count: int = 1):
+    """Device-tensor twin of count_distinct_sharded: `plain_t` (uint8, on this rank's GPU) is THIS rank's record-aligned share of
+    the PLAIN reads, already in HBM — nothing is uploaded; the local distinct set and the exchanged (key, count) pairs stay there
+    (one all-to-all under "nccl"). Returns this rank's share of the global distinct set as device int64 tensors."""
+    from . import counting
+    keys, counts = counting.count_distinct_t(plain_t, k, canon_mode, 1)
+    return exchange_merge_counts(keys, counts, min_count)
+
+
 def coverage_sharded(index, seqs, cutoff: int = 0):
     """Per-position tf profiles with the SEQUENCES split into contiguous ranges over the ranks (index replicated, no
     collective on the data path). Every rank returns (lo, hi, list of uint32 arrays) for its own range."""

@@ -598,6 +598,8 @@ def main():
     ap.add_argument("--reads", type=int, default=10_000_000)
     ap.add_argument("--cpu-sample", type=int, default=20_000_000)
     ap.add_argument("--cpu-reads", type=int, default=400_000, help="reads in the bounded CPU sample of the counting workloads")
+    ap.add_argument("--positions-tf", default="reads", choices=["reads", "genome"],
+                    help="positions23: tf of the index = occurrences in the reads (every found window is placed; the reference pipeline) or in the genome (tf = 1: first occurrences only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather-probe", action="store_true", help="skip the live random-read roofline measurement")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary counting measurement of the default workload")
@@ -929,8 +931,21 @@ def main():
     elif a.workload == "positions23":
         from aindex_amd._lib import lib, check, vp
         ix, g, keys, counts, pf = build_index23(a.genome, rank, world, dev, cache)
-        apply_ab_switches(ix, a)
         reads_t = engine.synth_reads_t(41, g, a.reads, 150, rc_half=True, n_rate_ppm=1000)
+        if a.positions_tf == "reads":
+            # the reference pipeline (kmer_counter -> compute_index -> compute_aindex) hands compute_aindex the tf of the READS, so every
+            # window of a stored k-mer is placed (positions array = 8 B per found window); with the genome's multiplicities (tf = 1 here)
+            # only the first occurrence of every k-mer would be written
+            from aindex_amd.engine import Index
+            tf_reads = torch.zeros(ix.n, dtype=torch.int32, device=f"cuda:{dev}")
+            ix.count23_fixed_t(reads_t, _lib.CANON_TRUE_RC, tf_reads)
+            torch.cuda.synchronize()
+            checker = ix.checker_array()
+            ix.close()
+            del keys, counts
+            ix = Index.create_23(pf, checker, tf_reads.cpu().numpy().view(np.uint32), dev)
+            del tf_reads, checker
+        apply_ab_switches(ix, a)
         res = {}
         step = lambda: res.__setitem__("o", ix.positions_fill_t(reads_t))
         wall, kern_ms, _ = timed_steps(step, a.steps, a.warmup, dev)
@@ -985,7 +1000,9 @@ def main():
         out.update({**({"cpu_baseline": cbp} if cbp else {}),
                     "metric": "reads_per_sec_positions_fill_23mer", "value": world * a.reads * a.steps / wall, "unit": "reads/s",
                     "ms_per_step": wall / a.steps * 1e3, "dtype": "u64",
-                    "config": {"workload": "A1+A2: positions index of 150 bp reads (resident in HBM) against the fixed 23-mer index",
+                    "config": {"workload": "A1+A2: positions index of 150 bp reads (resident in HBM) against the fixed 23-mer index; tf = occurrences in the "
+                                           + ("reads (every found window placed)" if a.positions_tf == "reads" else "genome (first occurrences only)"),
+                               "positions_tf": a.positions_tf,
                                "reads": a.reads, "windows": windows, "positions_total": int(indices[-1]), "filled": int((pos != 0).sum()),
                                "host_buffer_call_ms": host_dt * 1e3, "host_buffer_reads_per_s": a.reads / host_dt},
                     "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,

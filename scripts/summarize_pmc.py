@@ -21,11 +21,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TAGS = {
     "l23rand": ("lookup23:Q_rand", {"k_lookup23_ascii<0": 1}),
     "l23mix": ("lookup23:Q_mix", {"k_lookup23_ascii<0": 1}),
-    "c23": ("count23", {"k_probe23_slots": None, "k_c13_split_chunked<aix::SrcSlots>": None, "k_c13_hist_chunked": None}),
+    "c23": ("count23", {"k_probe23_slots": None, "k_c13_split_chunked<aix::SrcSlots": None, "k_c13_hist_chunked": None}),
     "cov23": ("coverage23", {"k_coverage": 1}),
-    "pos23": ("positions23", {"k_a2_probe": None, "k_a2_place": None, "k_a2_first": None, "radix_sort": None}),
+    "pos23": ("positions23", {"k_a2_probe": None, "k_k1_split<aix::A2Keys": None, "k_k1_count": None, "k_k1_scatter<unsigned long": None, "k_a2_final": None, "radix_sort": None}),
     "dist23": ("distinct23", {"k_window_codes": None, "k_k1_split": None, "k_k1_count": None, "k_k1_scatter": None, "k_k1_final": None, "k_k1_gather": None}),
-    "c13": ("count13", {"k_c13_split_chunked<aix::Src13>": None, "k_c13_hist_chunked": None}),
+    "c13": ("count13", {"k_c13_split_chunked<aix::Src13": None, "k_c13_hist_chunked": None}),
     "gather": (None, {"k_gather": 1}),
 }
 

@@ -83,6 +83,10 @@ def main():
         o = np.argsort(allk, kind="stable")
         fk, fc = O.count_distinct(fasta, k, mode, minc)
         assert fk.shape[0] > 100 and np.array_equal(allk[o], fk) and np.array_equal(allc[o], fc.astype(np.uint64)), (k, mode, minc)
+        mine = adist.shard_lines(plain, rank, world)                          # the same with this rank's share already resident
+        mt = torch.frombuffer(bytearray(mine) if mine else bytearray(1), dtype=torch.uint8)[: len(mine)].cuda()
+        tk, tc = adist.count_distinct_sharded_t(mt, k, mode, minc)
+        assert torch.equal(tk, sk) and torch.equal(tc, sc)
     # I1 across ranks: shard scatter on the GPU + max/sum merges == the reference's compute_index files
     full_checker = np.fromfile(prefix + ".kmers.bin", dtype=np.uint64)
     full_tf = np.fromfile(prefix + ".tf.bin", dtype=np.uint32)
