@@ -54,7 +54,7 @@ struct A2Over {                                       // head of the workspace
 // ---------------------------------------------------------------------------------------------
 // per bucket: counting sort by slot + rank by offset, all in LDS
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(A2_FB) k_a2_final(const IndexDev ix, const uint64_t* __restrict__ rem, const uint32_t* __restrict__ bucket_base, uint32_t nbuckets,
+__global__ void __launch_bounds__(A2_FB, 6) k_a2_final(const IndexDev ix, const uint64_t* __restrict__ rem, const uint32_t* __restrict__ bucket_base, uint32_t nbuckets,
                                                    uint32_t rbits, uint32_t cap_e, uint64_t piece_first, uint32_t* __restrict__ filled, int advance,
                                                    const uint64_t* __restrict__ indices, uint64_t* __restrict__ positions, A2Over* __restrict__ over,
                                                    uint32_t* __restrict__ over_b, uint64_t* __restrict__ over_off) {
