@@ -179,14 +179,18 @@ static __global__ void __launch_bounds__(K1_TB) k_k1_count(const uint64_t* __res
     h2[2 * t + 1] = 0;
     partition_range(spart, cap, p, range);
     const uint32_t lo = range[0], hi = range[1], dmask = nb2 - 1;
-    // 8 chunks per pass of the workgroup: 128 lanes per chunk, one entry each
-    for (uint32_t c0 = lo; c0 < hi; c0 += K1_TB / K1_CH) {
-        const uint32_t ci = c0 + (t >> 7);
-        if (ci < hi) {
-            const uint64_t desc = sdesc[ci];
-            const uint32_t id = (uint32_t)desc, fill = (uint32_t)(desc >> 32), o = t & (K1_CH - 1);
-            if (o < fill) atomicAdd(&h2[(uint32_t)(parts[(uint64_t)id * K1_CH + o] >> s2) & dmask], 1u);
-        }
+    // 64 chunks per pass of the workgroup (128 lanes per chunk, one entry each, eight chunks per lane): the eight descriptor loads and
+    // then the eight entry loads of a lane are independent, so a pass costs two memory latencies instead of sixteen
+    constexpr uint32_t U = 8, LANES_CH = K1_TB / K1_CH;
+    for (uint32_t c0 = lo; c0 < hi; c0 += U * LANES_CH) {
+        uint64_t desc[U], e[U];
+        const uint32_t o = t & (K1_CH - 1);
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) { const uint32_t ci = c0 + u * LANES_CH + (t >> 7); desc[u] = ci < hi ? sdesc[ci] : 0ull; }
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) e[u] = o < (uint32_t)(desc[u] >> 32) ? parts[(uint64_t)(uint32_t)desc[u] * K1_CH + o] : ~0ull;      // fill = 0 for chunks past hi
+#pragma unroll
+        for (uint32_t u = 0; u < U; ++u) if (e[u] != ~0ull) atomicAdd(&h2[(uint32_t)(e[u] >> s2) & dmask], 1u);
     }
     __syncthreads();
     for (uint32_t d = t; d < nb2; d += K1_TB) bucket_cnt[(uint64_t)p * nb2 + d] = h2[d];

@@ -1320,6 +1320,15 @@ def test_positions13_reference_pin_oracle_pieces_and_mirror(gold, tmp_path, monk
                 ind2, pos2 = ix.positions_fill(buf)
                 monkeypatch.delenv("AIX_POSITIONS_PIECE")
                 assert np.array_equal(pos2, opos), (len(buf), piece)
+            # the MSD grouping (the default from 2^22 windows up) on a 13-mer handle: 4^13 slots, u64 tf, forward-strand buckets; also
+            # with buckets set aside and cut into pieces
+            for env in ({"AIX_A2_MSD": "1"}, {"AIX_A2_MSD": "1", "AIX_A2_TEST_CAP": "5", "AIX_POSITIONS_PIECE": "50000"}):
+                for k_, v_ in env.items():
+                    monkeypatch.setenv(k_, v_)
+                ind3, pos3 = ix.positions_fill(buf)
+                for k_ in env:
+                    monkeypatch.delenv(k_)
+                assert np.array_equal(ind3, oind) and np.array_equal(pos3, opos), (len(buf), env)
             if buf:
                 t = torch.frombuffer(bytearray(buf), dtype=torch.uint8).cuda()
                 indt, post = ix.positions_fill_t(t)
