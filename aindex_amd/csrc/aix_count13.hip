@@ -2,7 +2,7 @@
 //
 // The 4^13 counter table (256 MiB as u32) is 1600x the LDS of a CU and 1.4e9 scattered memory-side atomics
 // run at ~23 G/s on MI355X (60 ms for 10 M reads). This path streams instead:
-//   k_c13_split_chunked : rolling 2-bit encode (32 window starts per lane, 4-byte SWAR); a 32 768-window tile is
+//   k_c13_split_chunked : rolling 2-bit encode (24 or 32 window starts per lane, 4-byte SWAR); a 12 288- or 32 768-window tile is
 //                         counting-sorted inside LDS by the top 11 code bits (rank from one ds_add_rtn per window) and each
 //                         partition's run of low-15-bit payloads (u16) is appended to the workgroup's current 256-entry chunk
 //                         of that partition; chunk ids come from a per-workgroup region, handed out by the tile's block scan
@@ -24,16 +24,23 @@ static constexpr int C13_PBITS = 11;
 static constexpr int C13_P = 1 << C13_PBITS;          // partitions
 static constexpr int C13_BINBITS = 26 - C13_PBITS;    // 15
 static constexpr int C13_BINS = 1 << C13_BINBITS;     // 32768 bins per partition
-static constexpr int C13_TB = 1024;                   // threads per workgroup
-static constexpr int C13_WPT = 32;                    // window starts per lane
-static constexpr int C13_TILE = C13_TB * C13_WPT;     // 32768 window starts per tile
+static constexpr int C13_TB = 1024;                   // threads per workgroup of the histogram kernel
 static constexpr int C13_DUMMY = 64;                  // scratch histogram bins for windows that do not count
 
-// Encode the C13_WPT windows whose starts are [S, S+WPT): the packed 2-bit stream (Run13::code<j>() = 26 bits) and a validity bit mask.
+// The split kernel comes in two shapes (template parameters TB = threads per workgroup, WPT = window starts per lane):
+//   1024 x 32: a 32 768-window tile, 152 KiB of LDS, ONE workgroup per CU — the default;
+//    512 x 24: a 12 288-window tile,  72 KiB of LDS, TWO workgroups per CU (AIX_C13_SHAPE=small). The kernel alternates VALU-bound
+//              phases (encode, write-out) with LDS-bound ones (the returning atomic per window, the tile scatter) between barriers,
+//              and PMC says the two add up (27 K + 16 K cycles per 32 K windows), so a second resident workgroup was
+//              expected to run its phases in the gaps. Measured on one box, alternating: 3.84 against 3.09 ms per 10 M reads for
+//              the 13-mer source, 1.60 against 1.17 ms per 2^28 slots: the per-tile work that does not shrink with the tile (a scan
+//              and three words for each of the 2 048 partitions, four per lane instead of two) costs more than the overlap returns.
+
+// Encode the WPT windows whose starts are [S, S+WPT): the packed 2-bit stream (Run13::code<j>() = 26 bits) and a validity bit mask.
 // Bytes at positions >= len count as separators. Upper-casing and the ACGT test follow
 // normalize_sequence / is_valid_kmer (count_kmers13.cpp:100-126).
 struct Run13 {
-    uint32_t w[3];        // 2-bit stream of the 44 bytes, base 0 in the top bits of w[0]; w[2] holds bases 32..43 in its top 24 bits
+    uint32_t w[3];        // 2-bit stream of the WPT + 12 bytes (<= 44), base 0 in the top bits of w[0]
     uint32_t valid;       // bit j: window j (bytes j..j+12) consists of bases only
     // 26-bit code of window j = stream bits [70 - 2j, 95 - 2j] of the 96-bit big-endian stream {w0, w1, w2}; two VALU
     // operations, so the windows are re-extracted where they are needed instead of being kept in 32 registers
@@ -49,25 +56,28 @@ struct Run13 {
     template <int J>
     __device__ __forceinline__ void get(uint32_t& c, uint32_t& ok) const { c = code<J>(); ok = (valid >> J) & 1u; }
 };
-template <int J, typename RUN, typename F>
+template <int WPT, int J, typename RUN, typename F>
 __device__ __forceinline__ void for_each_window13(const RUN& r, F&& f) {
-    if constexpr (J < C13_WPT) {
+    if constexpr (J < WPT) {
         uint32_t code, ok;
         r.template get<J>(code, ok);
         f(J, code, ok);
-        for_each_window13<J + 1>(r, f);
+        for_each_window13<WPT, J + 1>(r, f);
     }
 }
 
-// The 44 bytes behind window start S as eleven dwords (bytes at and past `len` read as separators); fetched on their own so that
-// the split kernel can have the NEXT tile's loads in flight while it writes the current one out.
+// The WPT + 12 bytes behind window start S as aligned dwords (bytes at and past `len` read as separators); fetched on their own so
+// that the split kernel can have the NEXT tile's loads in flight while it writes the current one out.
+template <int WPT>
 struct Raw13 {
-    uint32_t e[(C13_WPT + 12) / 4];
+    uint32_t e[(WPT + 12) / 4];
     uint64_t limit;                                   // bytes available from S (0: nothing)
 };
-__device__ __forceinline__ Raw13 fetch_raw13(const uint8_t* __restrict__ buf, uint64_t len, uint64_t S) {
-    constexpr int ND = (C13_WPT + 12) / 4;            // 11 aligned dwords
-    Raw13 r;
+template <int WPT>
+__device__ __forceinline__ Raw13<WPT> fetch_raw13(const uint8_t* __restrict__ buf, uint64_t len, uint64_t S) {
+    static_assert((WPT + 12) % 4 == 0 && WPT + 12 <= 48 && WPT <= 32, "the stream is three dwords, the validity mask one");
+    constexpr int ND = (WPT + 12) / 4;
+    Raw13<WPT> r;
     r.limit = S < len ? len - S : 0;
 #pragma unroll
     for (int k = 0; k < ND; ++k) r.e[k] = 0x0A0A0A0Au;
@@ -83,8 +93,9 @@ __device__ __forceinline__ Raw13 fetch_raw13(const uint8_t* __restrict__ buf, ui
     for (int k = 0; k < ND; ++k) r.e[k] = __funnelshift_r(d[k], d[k + 1], sh);
     return r;
 }
-__device__ __forceinline__ Run13 encode_raw13(const Raw13& raw) {
-    constexpr int NB = C13_WPT + 12;                  // 44 bytes
+template <int WPT>
+__device__ __forceinline__ Run13 encode_raw13(const Raw13<WPT>& raw) {
+    constexpr int NB = WPT + 12;
     constexpr int ND = NB / 4;
     Run13 r{{0, 0, 0}, 0};
     if (raw.limit == 0) return r;
@@ -107,23 +118,28 @@ __device__ __forceinline__ Run13 encode_raw13(const Raw13& raw) {
     if (raw.limit < (uint64_t)NB) vmask &= (1ull << raw.limit) - 1;   // bytes at and past the end of the buffer are separators
     // window j (bytes j..j+12) is countable iff 13 consecutive mask bits are set
     const uint64_t m2 = vmask & (vmask >> 1), m4 = m2 & (m2 >> 2), m8 = m4 & (m4 >> 4);
-    r.valid = (uint32_t)(m8 & (m4 >> 8) & (vmask >> 12));
+    uint64_t ok = m8 & (m4 >> 8) & (vmask >> 12);
+    if (WPT < 32) ok &= (1ull << WPT) - 1;
+    r.valid = (uint32_t)ok;
     return r;
 }
 
-// What the split kernel sorts: 32 keys of at most 26 bits per lane and tile, with a validity bit each.
+// What the split kernel sorts: WPT keys of at most 26 bits per lane and tile, with a validity bit each.
 struct Src13 {                                        // the 13-mer windows of a PLAIN reads buffer (count_kmers13)
     const uint8_t* buf;
     uint64_t len;
-    __device__ __forceinline__ Raw13 fetch(uint64_t tile, int t) const { return fetch_raw13(buf, len, tile * C13_TILE + (uint64_t)t * C13_WPT); }
-    __device__ __forceinline__ Run13 decode(const Raw13& raw) const { return encode_raw13(raw); }
+    template <int TB, int WPT>
+    __device__ __forceinline__ Raw13<WPT> fetch(uint64_t tile, int t) const { return fetch_raw13<WPT>(buf, len, tile * (uint64_t)(TB * WPT) + (uint64_t)t * WPT); }
+    template <int TB, int WPT>
+    __device__ __forceinline__ Run13 decode(const Raw13<WPT>& raw) const { return encode_raw13<WPT>(raw); }
 };
-struct RunSlots {                                     // element j of this lane = p[j * 1024]: every load instruction of the workgroup reads 4 KiB of
+template <int TB>
+struct RunSlots {                                     // element j of this lane = p[j * TB]: every load instruction of the workgroup reads 4 * TB bytes of
     const uint32_t* p;                                // consecutive slots. Nothing is kept in registers between the two passes of the tile sort
-    uint32_t limit;                                   // (32 more live registers spill): the second pass re-reads the 128 KiB tile through L2
+    uint32_t limit;                                   // (WPT more live registers spill): the second pass re-reads the tile through L2
     template <int J>
     __device__ __forceinline__ void get(uint32_t& c, uint32_t& ok) const {
-        const uint32_t v = (uint32_t)(J * C13_TB) < limit ? p[J * C13_TB] : 0xFFFFFFFFu;
+        const uint32_t v = (uint32_t)(J * TB) < limit ? p[J * TB] : 0xFFFFFFFFu;
         c = v & 0x3FFFFFFu;
         ok = v != 0xFFFFFFFFu ? 1u : 0u;
     }
@@ -131,14 +147,16 @@ struct RunSlots {                                     // element j of this lane 
 struct SrcSlots {                                     // a stream of MPHF slots (< 2^26) in HBM, 0xFFFFFFFF = nothing to count (count23)
     const uint32_t* slots;
     uint64_t n;
-    __device__ __forceinline__ RunSlots fetch(uint64_t tile, int t) const {      // nothing is fetched ahead: the passes read the stream themselves
-        const uint64_t base = tile * C13_TILE + (uint64_t)t;
-        RunSlots r;
+    template <int TB, int WPT>
+    __device__ __forceinline__ RunSlots<TB> fetch(uint64_t tile, int t) const {  // nothing is fetched ahead: the passes read the stream themselves
+        const uint64_t base = tile * (uint64_t)(TB * WPT) + (uint64_t)t;
+        RunSlots<TB> r;
         r.p = slots + base;
-        r.limit = base < n ? (uint32_t)min((uint64_t)C13_TILE, n - base) : 0u;   // elements [0, limit) of p are inside the stream
+        r.limit = base < n ? (uint32_t)min((uint64_t)(TB * WPT), n - base) : 0u;  // elements [0, limit) of p are inside the stream
         return r;
     }
-    __device__ __forceinline__ RunSlots decode(const RunSlots& r) const { return r; }
+    template <int TB, int WPT>
+    __device__ __forceinline__ RunSlots<TB> decode(const RunSlots<TB>& r) const { return r; }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -151,15 +169,18 @@ static constexpr int C13_CH = 256;                    // entries per chunk (512 
 static constexpr int C13_INFLIGHT = 8;                // chunk loads a wave of the histogram kernel keeps in flight
 static constexpr int C13_FILLBITS = 9;                // cursor = (chunk << 9) | fill, fill in [0, 256]; chunk = index inside the workgroup's region (< 2^23)
 
-// Chunk ids need no global allocator: a workgroup that sorts T tiles fills at most T * 128 + 2048 chunks (entries / 256
+// Chunk ids need no global allocator: a workgroup that sorts T tiles fills at most T * TILE / 256 + 2048 chunks (entries / 256
 // plus one partly filled chunk per partition), so workgroup b owns chunk ids [b * region, (b + 1) * region) and hands them
 // out with the same block scan that orders the tile (the per-partition chunk demand rides in the high half of the scan).
-// A chunk id at or past `region` cannot happen while chunk_region() is right; if it ever does, the write is dropped AND `err`
-// is raised, so the call fails with AIX_ERR_UNSUPPORTED instead of returning short counts.
-template <class SRC, bool PREFETCH>
-__global__ void __launch_bounds__(C13_TB) k_c13_split_chunked(const SRC src, uint64_t ntiles, uint32_t region,
-                                                             uint16_t* __restrict__ dir_part, uint16_t* __restrict__ dir_cnt, uint16_t* __restrict__ parts,
-                                                             uint32_t* __restrict__ err) {
+// Chunk ids are handed out contiguously, so "every fresh chunk of this tile lies inside the region" is ONE uniform test per tile;
+// a tile that fails it is dropped whole AND `err` is raised: the call fails with AIX_ERR_UNSUPPORTED instead of returning short counts.
+template <class SRC, int TB, int WPT, bool PREFETCH>
+__global__ void __launch_bounds__(TB) k_c13_split_chunked(const SRC src, uint64_t ntiles, uint32_t region,
+                                                         uint16_t* __restrict__ dir_part, uint16_t* __restrict__ dir_cnt, uint16_t* __restrict__ parts,
+                                                         uint32_t* __restrict__ err) {
+    constexpr int TILE = TB * WPT;
+    constexpr int PPL = C13_P / TB;                             // partitions a lane owns: PPL * t .. PPL * t + PPL - 1
+    static_assert(C13_P % TB == 0 && TB % 64 == 0 && TILE <= 32768 && TILE / C13_CH + C13_P < 65536 && WPT % 2 == 0, "one packed 16 + 16 bit scan per tile");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint32_t* hist = (uint32_t*)smem;                           // [P + DUMMY] tile-local count per partition; after the scan: write-out delta A of the partition
     uint32_t* loc_t = hist + C13_P + C13_DUMMY;                 // [P] exclusive scan of hist (low half) | first tile index that no longer fits the current chunk (high half)
@@ -170,31 +191,33 @@ __global__ void __launch_bounds__(C13_TB) k_c13_split_chunked(const SRC src, uin
     constexpr uint32_t FILLMASK = (1u << C13_FILLBITS) - 1;
     const uint32_t region_base = blockIdx.x * region;           // chunk ids below are relative to it
     uint32_t next_chunk = 0;                                    // same value in every lane
-    // this lane owns partitions 2t and 2t+1 for the whole kernel: their cursors, (current chunk << 9) | entries used in it (256 = none / full),
-    // never leave its registers
-    uint32_t cur0 = C13_CH, cur1 = C13_CH;
-    hist[2 * t] = 0;
-    hist[2 * t + 1] = 0;
+    // the cursors of the partitions this lane owns, (current chunk << 9) | entries used in it (256 = none / full), never leave its registers
+    uint32_t cur[PPL];
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) { cur[q] = C13_CH; hist[PPL * t + q] = 0; }
     if (t < C13_DUMMY) hist[C13_P + t] = 0;
     __syncthreads();
-    auto raw = src.fetch(blockIdx.x, t);
+    auto raw = src.template fetch<TB, WPT>(blockIdx.x, t);
     for (uint64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        uint32_t rank[C13_WPT / 2];                              // two 16-bit ranks per register
-        if constexpr (!PREFETCH) raw = src.fetch(tile, t);
-        const auto run = src.decode(raw);
+        uint32_t rank[WPT / 2];                                  // two 16-bit ranks per register
+        if constexpr (!PREFETCH) raw = src.template fetch<TB, WPT>(tile, t);
+        const auto run = src.template decode<TB, WPT>(raw);
         const uint32_t dummy = C13_P + (t & (C13_DUMMY - 1));
-        for_each_window13<0>(run, [&](int j, uint32_t code, uint32_t ok) {
+        for_each_window13<WPT, 0>(run, [&](int j, uint32_t code, uint32_t ok) {
             const uint32_t r = atomicAdd(&hist[ok ? code >> C13_BINBITS : dummy], 1u);
             if (j & 1) rank[j >> 1] |= r << 16; else rank[j >> 1] = r;
         });
         __syncthreads();
-        // entries a, b of the two partitions this lane owns; fresh chunks k0, k1 = by how much they overflow the current chunk
-        const uint32_t a = hist[2 * t], b = hist[2 * t + 1];
-        const uint32_t f0 = cur0 & FILLMASK, f1 = cur1 & FILLMASK;
-        const uint32_t tot0 = f0 + a, tot1 = f1 + b;
-        const uint32_t k0 = tot0 > (uint32_t)C13_CH ? (tot0 - 1) / C13_CH : 0u;    // = ceil((tot - CH) / CH)
-        const uint32_t k1 = tot1 > (uint32_t)C13_CH ? (tot1 - 1) / C13_CH : 0u;
-        uint32_t s = (a + b) | ((k0 + k1) << 16);               // one scan for both: a tile has <= 32768 entries and needs <= 2176 fresh chunks
+        // entries a[q] of the partitions this lane owns; fresh chunks k[q] = by how much they overflow the current chunk
+        uint32_t a[PPL], f[PPL], tot[PPL], k[PPL], s = 0;
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) {
+            a[q] = hist[PPL * t + q];
+            f[q] = cur[q] & FILLMASK;
+            tot[q] = f[q] + a[q];
+            k[q] = tot[q] > (uint32_t)C13_CH ? (tot[q] - 1) / C13_CH : 0u;       // = ceil((tot - CH) / CH)
+            s += a[q] | (k[q] << 16);                            // one scan for both: a tile has <= 32768 entries and needs <= 2176 fresh chunks
+        }
         const uint32_t mine = s;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -202,37 +225,35 @@ __global__ void __launch_bounds__(C13_TB) k_c13_split_chunked(const SRC src, uin
             if ((t & 63) >= d) s += y;
         }
         if ((t & 63) == 63) wsum[t >> 6] = s;
-        __syncthreads();                                         // every lane has read its two counters: hist may be overwritten
+        __syncthreads();                                         // every lane has read its counters: hist may be overwritten
         uint32_t off = 0, all = 0;
-        for (int w = 0; w < C13_TB / 64; ++w) {
+#pragma unroll
+        for (int w = 0; w < TB / 64; ++w) {
             const uint32_t x = wsum[w];
             if (w < (t >> 6)) off += x;
             all += x;
         }
         const uint32_t entries = all & 0xFFFFu;
-        // Chunk ids are handed out contiguously, so "every fresh chunk of this tile lies inside the region" is one uniform test.
-        // A tile that fails it is dropped as a whole AND `err` is raised: the call fails with AIX_ERR_UNSUPPORTED, never short counts.
         const bool fits = next_chunk + (all >> 16) <= region;
         if (!fits && t == 0) *err = 1u;
-        const uint32_t excl = off + s - mine;
-        const uint32_t e0 = excl & 0xFFFFu, e1 = e0 + a, nb0 = next_chunk + (excl >> 16), nb1 = nb0 + k0;
+        uint32_t excl = off + s - mine;
         // where the entries of a partition go, as two deltas to their index i inside the sorted tile: i < T lands in the current
         // chunk at A + i, the rest in the fresh chunks (consecutive ids) at B + i
-        loc_t[2 * t] = e0 | ((e0 + C13_CH - f0) << 16);          // T <= 32768 + 256
-        loc_t[2 * t + 1] = e1 | ((e1 + C13_CH - f1) << 16);
-        hist[2 * t] = (cur0 >> C13_FILLBITS) * C13_CH + f0 - e0;
-        hist[2 * t + 1] = (cur1 >> C13_FILLBITS) * C13_CH + f1 - e1;
-        delta_b[2 * t] = nb0 * C13_CH + f0 - e0 - C13_CH;
-        delta_b[2 * t + 1] = nb1 * C13_CH + f1 - e1 - C13_CH;
-        if (fits) {
-            for (uint32_t i = 0; i < k0; ++i) dir_part[region_base + nb0 + i] = (uint16_t)(2 * t);        // fill stays at the pre-set 256
-            for (uint32_t i = 0; i < k1; ++i) dir_part[region_base + nb1 + i] = (uint16_t)(2 * t + 1);    // unless it ends up the last one
-            cur0 = k0 ? ((nb0 + k0 - 1) << C13_FILLBITS) | (tot0 - k0 * C13_CH) : (cur0 & ~FILLMASK) | tot0;
-            cur1 = k1 ? ((nb1 + k1 - 1) << C13_FILLBITS) | (tot1 - k1 * C13_CH) : (cur1 & ~FILLMASK) | tot1;
-            next_chunk += all >> 16;
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) {
+            const uint32_t p = PPL * t + q, e0 = excl & 0xFFFFu, nb = next_chunk + (excl >> 16);
+            loc_t[p] = e0 | ((e0 + C13_CH - f[q]) << 16);        // T <= 32768 + 256
+            hist[p] = (cur[q] >> C13_FILLBITS) * C13_CH + f[q] - e0;
+            delta_b[p] = nb * C13_CH + f[q] - e0 - C13_CH;
+            if (fits) {
+                for (uint32_t i = 0; i < k[q]; ++i) dir_part[region_base + nb + i] = (uint16_t)p;      // fill stays at the pre-set 256 unless it ends up the last one
+                cur[q] = k[q] ? ((nb + k[q] - 1) << C13_FILLBITS) | (tot[q] - k[q] * C13_CH) : (cur[q] & ~FILLMASK) | tot[q];
+            }
+            excl += a[q] | (k[q] << 16);
         }
+        if (fits) next_chunk += all >> 16;
         __syncthreads();                                         // the per-partition words are complete
-        for_each_window13<0>(run, [&](int j, uint32_t code, uint32_t ok) {
+        for_each_window13<WPT, 0>(run, [&](int j, uint32_t code, uint32_t ok) {
             if (ok) {
                 const uint32_t p = code >> C13_BINBITS;
                 const uint32_t r = (j & 1) ? (rank[j >> 1] >> 16) : (rank[j >> 1] & 0xFFFFu);
@@ -240,10 +261,10 @@ __global__ void __launch_bounds__(C13_TB) k_c13_split_chunked(const SRC src, uin
             }
         });
         __syncthreads();
-        if constexpr (PREFETCH) { if (tile + gridDim.x < ntiles) raw = src.fetch(tile + gridDim.x, t); }      // in flight while this tile is written out
+        if constexpr (PREFETCH) { if (tile + gridDim.x < ntiles) raw = src.template fetch<TB, WPT>(tile + gridDim.x, t); }      // in flight while this tile is written out
         if (fits) {
             uint16_t* const out = parts + (uint64_t)region_base * C13_CH;
-            for (uint32_t i = t; i < entries; i += C13_TB) {
+            for (uint32_t i = t; i < entries; i += TB) {
                 const uint32_t e = sorted[i];
                 const uint32_t p = e >> 16;
                 const uint32_t d = i < (loc_t[p] >> 16) ? hist[p] : delta_b[p];
@@ -251,16 +272,16 @@ __global__ void __launch_bounds__(C13_TB) k_c13_split_chunked(const SRC src, uin
             }
         }
         __syncthreads();
-        hist[2 * t] = 0;
-        hist[2 * t + 1] = 0;
+#pragma unroll
+        for (int q = 0; q < PPL; ++q) hist[PPL * t + q] = 0;
         if (t < C13_DUMMY) hist[C13_P + t] = 0;
         __syncthreads();
     }
     // the chunk each (workgroup, partition) pair was still filling is the only one that is not full
-    {
-        const uint32_t fl0 = cur0 & FILLMASK, fl1 = cur1 & FILLMASK;
-        if (fl0 < (uint32_t)C13_CH) dir_cnt[region_base + (cur0 >> C13_FILLBITS)] = (uint16_t)fl0;
-        if (fl1 < (uint32_t)C13_CH) dir_cnt[region_base + (cur1 >> C13_FILLBITS)] = (uint16_t)fl1;
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {
+        const uint32_t fl = cur[q] & FILLMASK;
+        if (fl < (uint32_t)C13_CH) dir_cnt[region_base + (cur[q] >> C13_FILLBITS)] = (uint16_t)fl;
     }
 }
 
@@ -334,19 +355,32 @@ struct ChunkDesc {
     __host__ __device__ uint64_t operator()(uint32_t i) const { return (uint64_t)i | ((uint64_t)dir_cnt[i] << 32); }
 };
 
-static constexpr unsigned C13_MAXGRID = 512;
+// shape of the split kernel for this process (A/B switch AIX_C13_SHAPE=big|small): tile size, workgroups that are resident at once
+struct C13Shape { int tb, wpt; unsigned maxgrid; };
+static inline C13Shape c13_shape() {
+    static const C13Shape sh = [] {
+        C13Shape v{1024, 32, 512};                                // one 152 KiB workgroup per CU: measured faster than two smaller ones (see the top of the file)
+        if (const char* e = getenv("AIX_C13_SHAPE")) { if (e[0] == 's') v = C13Shape{512, 24, 1024}; }
+        return v;
+    }();
+    return sh;
+}
 
 static inline uint64_t align_up(uint64_t x, uint64_t a) { return (x + a - 1) / a * a; }
-// chunk ids one workgroup can need: 128 per tile it sorts + one partly filled chunk per partition
+// chunk ids one workgroup can need: TILE / 256 per tile it sorts + one partly filled chunk per partition
 static inline uint32_t chunk_region(uint64_t nwin) {
     if (const char* e = getenv("AIX_COUNT13_TEST_REGION")) { const long v = atol(e); if (v > 0) return (uint32_t)v; }   // test hook: an undersized region must fail loudly
-    const uint64_t ntiles = (nwin + C13_TILE - 1) / C13_TILE;
-    const uint64_t grid = std::min<uint64_t>(ntiles ? ntiles : 1, C13_MAXGRID);
-    return (uint32_t)((ntiles + grid - 1) / grid * (C13_TILE / C13_CH) + C13_P);
+    const C13Shape sh = c13_shape();
+    const uint64_t tile = (uint64_t)sh.tb * sh.wpt;
+    const uint64_t ntiles = (nwin + tile - 1) / tile;
+    const uint64_t grid = std::min<uint64_t>(ntiles ? ntiles : 1, sh.maxgrid);
+    return (uint32_t)((ntiles + grid - 1) / grid * ((tile + C13_CH - 1) / C13_CH) + C13_P);
 }
 static inline uint32_t chunk_capacity(uint64_t nwin) {
-    const uint64_t ntiles = (nwin + C13_TILE - 1) / C13_TILE;
-    return (uint32_t)(std::min<uint64_t>(ntiles ? ntiles : 1, C13_MAXGRID) * chunk_region(nwin));
+    const C13Shape sh = c13_shape();
+    const uint64_t tile = (uint64_t)sh.tb * sh.wpt;
+    const uint64_t ntiles = (nwin + tile - 1) / tile;
+    return (uint32_t)(std::min<uint64_t>(ntiles ? ntiles : 1, sh.maxgrid) * chunk_region(nwin));
 }
 static size_t dir_sort_temp_bytes(uint32_t cap) {
     size_t bytes = 0;
@@ -361,6 +395,23 @@ uint64_t count13_workspace_bytes(uint64_t len) {
     const uint64_t nwin = len >= 13 ? len - 12 : 0;
     const uint64_t cap = chunk_capacity(nwin);
     return 256 + 3 * align_up(2 * cap, 256) + align_up(8 * cap, 256) + align_up(dir_sort_temp_bytes((uint32_t)cap), 256) + 2 * cap * C13_CH + 256;
+}
+
+template <class SRC, int TB, int WPT>
+static hipError_t launch_split(const SRC& src, uint64_t ntiles, unsigned grid, uint32_t region, uint16_t* dir_part, uint16_t* dir_cnt, uint16_t* parts, uint32_t* err,
+                               hipStream_t s) {
+    constexpr size_t lds = 4 * (3 * C13_P + C13_DUMMY + 16) + 4 * (size_t)TB * WPT;       // 155 968 B (1024 x 32) / 74 048 B (512 x 24)
+    // the next tile's loads in flight during the write-out: measured SLOWER for the 13-mer source (3.45 against 3.10 ms per 10 M reads: eleven more
+    // live registers put the kernel at its 128-VGPR limit), so it is off unless asked for (A/B switch); the slot source has nothing to fetch ahead
+    bool prefetch = false;
+    if (const char* pf = getenv("AIX_C13_PREFETCH")) prefetch = atoi(pf) != 0;
+    // > 64 KiB of dynamic LDS needs the attribute; set per call (cheap, and correct for every device / thread)
+    hipError_t e = prefetch ? hipFuncSetAttribute((const void*)k_c13_split_chunked<SRC, TB, WPT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                            : hipFuncSetAttribute((const void*)k_c13_split_chunked<SRC, TB, WPT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    if (prefetch) hipLaunchKernelGGL((k_c13_split_chunked<SRC, TB, WPT, true>), dim3(grid), dim3(TB), lds, s, src, ntiles, region, dir_part, dir_cnt, parts, err);
+    else hipLaunchKernelGGL((k_c13_split_chunked<SRC, TB, WPT, false>), dim3(grid), dim3(TB), lds, s, src, ntiles, region, dir_part, dir_cnt, parts, err);
+    return hipGetLastError();
 }
 
 template <class SRC>
@@ -378,27 +429,18 @@ static hipError_t partitioned_histogram(const SRC& src, uint64_t nwin, void* wor
     size_t tmp_bytes = dir_sort_temp_bytes(cap);
     void* tmp = w;                                            w += align_up(tmp_bytes, 256);
     uint16_t* parts = (uint16_t*)w;
-    const uint64_t ntiles = (nwin + C13_TILE - 1) / C13_TILE;
-    const unsigned grid = (unsigned)std::min<uint64_t>(ntiles ? ntiles : 1, C13_MAXGRID);
+    const C13Shape sh = c13_shape();
+    const uint64_t tile = (uint64_t)sh.tb * sh.wpt;
+    const uint64_t ntiles = (nwin + tile - 1) / tile;
+    const unsigned grid = (unsigned)std::min<uint64_t>(ntiles ? ntiles : 1, sh.maxgrid);
     const size_t hist_lds = 4 * C13_BINS;                                       // 131 072 B
-    const size_t split_lds = 4 * (3 * C13_P + C13_DUMMY + 16) + 4 * C13_TILE;   // 155 968 B
-    {   // > 64 KiB of dynamic LDS needs the attribute; set per call (cheap, and correct for every device / thread)
-        hipError_t e = hipFuncSetAttribute((const void*)k_c13_hist_chunked, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)k_c13_split_chunked<SRC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)split_lds);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)k_c13_split_chunked<SRC, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)split_lds);
-        if (e != hipSuccess) return e;
-    }
-    hipError_t e = hipMemsetD16Async((hipDeviceptr_t)dir_part, (unsigned short)C13_P, cap, s);     // "no partition": sorts behind every real one
+    hipError_t e = hipFuncSetAttribute((const void*)k_c13_hist_chunked, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hist_lds);
+    if (e == hipSuccess) e = hipMemsetD16Async((hipDeviceptr_t)dir_part, (unsigned short)C13_P, cap, s);     // "no partition": sorts behind every real one
     if (e == hipSuccess) e = hipMemsetD16Async((hipDeviceptr_t)dir_cnt, (unsigned short)C13_CH, cap, s);     // chunks are full unless the split says otherwise
     if (e != hipSuccess) return e;
-    // the next tile's loads in flight during the write-out: measured SLOWER for the 13-mer source (3.45 against 3.10 ms per 10 M reads: eleven more
-    // live registers put the kernel at its 128-VGPR limit), so it is off unless asked for (A/B switch); the slot source has nothing to fetch ahead
-    bool prefetch = false;
-    if (const char* pf = getenv("AIX_C13_PREFETCH")) prefetch = atoi(pf) != 0;
-    if (prefetch) hipLaunchKernelGGL((k_c13_split_chunked<SRC, true>), dim3(grid), dim3(C13_TB), split_lds, s, src, ntiles, chunk_region(nwin), dir_part, dir_cnt, parts, err);
-    else hipLaunchKernelGGL((k_c13_split_chunked<SRC, false>), dim3(grid), dim3(C13_TB), split_lds, s, src, ntiles, chunk_region(nwin), dir_part, dir_cnt, parts, err);
+    if (sh.tb == 512) e = launch_split<SRC, 512, 24>(src, ntiles, grid, chunk_region(nwin), dir_part, dir_cnt, parts, err, s);
+    else e = launch_split<SRC, 1024, 32>(src, ntiles, grid, chunk_region(nwin), dir_part, dir_cnt, parts, err, s);
+    if (e != hipSuccess) return e;
     auto vals = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), ChunkDesc{dir_cnt});
     e = rocprim::radix_sort_pairs(tmp, tmp_bytes, (const uint16_t*)dir_part, spart, vals, sdesc, (size_t)cap, 0u, 12u, s);
     if (e != hipSuccess) return e;
