@@ -103,7 +103,8 @@ hipError_t distinct_from_codes(uint64_t* d_codes, uint64_t nwin, int k, uint64_t
 // *fell_back: a bucket held too many distinct remainders; nothing was produced and the caller takes the radix-sort path.
 bool k1_msd_eligible(uint64_t nwin, int k);
 hipError_t distinct_from_codes_msd(uint64_t* d_codes, uint64_t nwin, int k, uint64_t** d_keys_out, uint32_t** d_counts_out, uint64_t* n_out, bool* fell_back,
-                                   hipStream_t s, const uint8_t* d_plain = nullptr /* encode inside level 1 */, uint64_t plen = 0, int canon_mode = 0);
+                                   hipStream_t s, const uint8_t* d_plain = nullptr /* encode inside level 1 */, uint64_t plen = 0, int canon_mode = 0,
+                                   uint64_t** d_counts64_out = nullptr /* non-null: the counts come back as u64 here, *d_counts_out stays null */);
 hipError_t distinct_from_plain(const uint8_t* d_plain, uint64_t plen, int k, int canon_mode, uint64_t min_count, uint64_t piece, uint64_t** d_keys_out,
                                uint64_t** d_counts_out, uint64_t* n_out, hipStream_t s);
 hipError_t merge_counts(const uint64_t* d_keys, const uint64_t* d_counts, uint64_t n, uint64_t min_count, uint64_t** d_keys_out, uint64_t** d_counts_out,

@@ -243,13 +243,15 @@ __global__ void __launch_bounds__(K1_FB) k_k1_final(const uint32_t* __restrict__
 }
 
 // buckets closed up: bucket b's m entries move from its base to dm_off[b]; one wave per bucket
+// CNT = uint32_t (the ABI's per-piece result) or uint64_t (what the merge of pieces and kmer_counter's output carry: written here, no widening pass)
+template <typename CNT>
 __global__ void __launch_bounds__(256) k_k1_gather(const uint64_t* __restrict__ keys_st, const uint32_t* __restrict__ cnt_st, const uint32_t* __restrict__ bucket_base,
-                                                  const uint32_t* __restrict__ dm_off, uint32_t nbuckets, uint64_t* __restrict__ keys, uint32_t* __restrict__ counts) {
+                                                  const uint32_t* __restrict__ dm_off, uint32_t nbuckets, uint64_t* __restrict__ keys, CNT* __restrict__ counts) {
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t nw = (uint64_t)gridDim.x * 4;
     for (uint64_t b = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); b < nbuckets; b += nw) {
         const uint32_t src = bucket_base[b], dst = dm_off[b], m = dm_off[b + 1] - dst;
-        for (uint32_t i = lane; i < m; i += 64) { keys[dst + i] = keys_st[src + i]; counts[dst + i] = cnt_st[src + i]; }
+        for (uint32_t i = lane; i < m; i += 64) { keys[dst + i] = keys_st[src + i]; counts[dst + i] = (CNT)cnt_st[src + i]; }
     }
 }
 
@@ -269,8 +271,9 @@ bool k1_msd_eligible(uint64_t nwin, int k) {
 // d_plain != nullptr: the windows are encoded inside level 1 (no code array is read; d_codes is then only the 8 B-per-window
 // scratch the later stages re-use). plen = bytes of the PLAIN buffer.
 hipError_t distinct_from_codes_msd(uint64_t* d_codes, uint64_t nwin, int k, uint64_t** d_keys_out, uint32_t** d_counts_out, uint64_t* n_out, bool* fell_back,
-                                   hipStream_t s, const uint8_t* d_plain, uint64_t plen, int canon_mode) {
+                                   hipStream_t s, const uint8_t* d_plain, uint64_t plen, int canon_mode, uint64_t** d_counts64_out) {
     *d_keys_out = nullptr; *d_counts_out = nullptr; *n_out = 0; *fell_back = false;
+    if (d_counts64_out) *d_counts64_out = nullptr;
     const uint32_t B = 2u * (uint32_t)k, s1 = B - K1_PBITS;
     // D2: ~768 codes per bucket on average; the remainder must fit 32 bits
     uint32_t D2 = 3;
@@ -356,10 +359,13 @@ hipError_t distinct_from_codes_msd(uint64_t* d_codes, uint64_t nwin, int k, uint
         if (flags[1]) { *fell_back = true; break; }
         if (total_distinct == 0) break;
         e = pool_alloc((void**)&keys, 8ull * total_distinct);
-        if (e == hipSuccess) e = pool_alloc((void**)&counts, 4ull * total_distinct);
+        if (e == hipSuccess) e = pool_alloc((void**)&counts, (d_counts64_out ? 8ull : 4ull) * total_distinct);
         if (e != hipSuccess) break;
-        hipLaunchKernelGGL(k_k1_gather, dim3(std::min<uint32_t>((nbuckets + 3) / 4, 1u << 16)), dim3(256), 0, s, (const uint64_t*)keys_st, (const uint32_t*)cnt_st,
-                           (const uint32_t*)bucket_base, (const uint32_t*)dm_off, nbuckets, keys, counts);
+        const dim3 ggrid(std::min<uint32_t>((nbuckets + 3) / 4, 1u << 16));
+        if (d_counts64_out) hipLaunchKernelGGL(k_k1_gather<uint64_t>, ggrid, dim3(256), 0, s, (const uint64_t*)keys_st, (const uint32_t*)cnt_st, (const uint32_t*)bucket_base,
+                                               (const uint32_t*)dm_off, nbuckets, keys, (uint64_t*)counts);
+        else hipLaunchKernelGGL(k_k1_gather<uint32_t>, ggrid, dim3(256), 0, s, (const uint64_t*)keys_st, (const uint32_t*)cnt_st, (const uint32_t*)bucket_base,
+                                (const uint32_t*)dm_off, nbuckets, keys, counts);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(s);
     } while (false);
@@ -370,7 +376,8 @@ hipError_t distinct_from_codes_msd(uint64_t* d_codes, uint64_t nwin, int k, uint
         if (counts) pool_free(counts);
         return e;
     }
-    *d_keys_out = keys; *d_counts_out = counts; *n_out = total_distinct;
+    *d_keys_out = keys; *n_out = total_distinct;
+    if (d_counts64_out) { *d_counts64_out = (uint64_t*)counts; *d_counts_out = nullptr; } else *d_counts_out = counts;
     return hipSuccess;
 }
 

@@ -368,19 +368,24 @@ hipError_t distinct_from_plain(const uint8_t* d_plain, uint64_t plen, int k, int
         DevArr codes(s);
         e = codes.alloc(8 * nwin);
         uint64_t* pk = nullptr; uint32_t* pc = nullptr; uint64_t pm = 0;
+        uint64_t* pc64 = nullptr;                                             // the MSD path hands its counts over as u64 (no widening pass)
         bool sorted_path = !k1_msd_eligible(nwin, k);
         if (e == hipSuccess && sorted_path) e = launch_window_codes(d_plain + w0, nwin + k - 1, k, canon_mode, (uint64_t*)codes.p, s);
         if (e == hipSuccess && !sorted_path) {                                // MSD partition + per-bucket LDS hash / sort (aix_k1.hip); windows encoded inside level 1
             bool fell_back = false;
-            e = distinct_from_codes_msd((uint64_t*)codes.p, nwin, k, &pk, &pc, &pm, &fell_back, s, d_plain + w0, nwin + k - 1, canon_mode);
+            e = distinct_from_codes_msd((uint64_t*)codes.p, nwin, k, &pk, &pc, &pm, &fell_back, s, d_plain + w0, nwin + k - 1, canon_mode, &pc64);
             if (e == hipSuccess && fell_back) {                               // a bucket too rich for LDS: the codes were used as staging, make them again
                 sorted_path = true;
                 e = launch_window_codes(d_plain + w0, nwin + k - 1, k, canon_mode, (uint64_t*)codes.p, s);
             }
         }
         if (e == hipSuccess && sorted_path) e = distinct_from_codes((uint64_t*)codes.p, nwin, k, 1, &pk, &pc, &pm, s);
-        DevArr hold_k(s), hold_c(s); hold_k.p = pk; hold_c.p = pc;
+        DevArr hold_k(s), hold_c(s), hold_c64(s); hold_k.p = pk; hold_c.p = pc; hold_c64.p = pc64;
         if (e != hipSuccess || pm == 0) continue;
+        if (acc_n == 0 && pc64) {                                             // first non-empty piece from the MSD path: sorted, distinct, u64 counts — taken as it is
+            acc_k.p = hold_k.release(); acc_c.p = hold_c64.release(); acc_n = pm;
+            continue;
+        }
         // concatenate {acc, piece} as (key, u64 count), sort by key, sum equal keys
         const uint64_t tot = acc_n + pm;
         if (tot >> 32) { e = hipErrorInvalidValue; continue; }                // rocPRIM reduce_by_key takes a 32-bit size: < 2^32 distinct k-mers
@@ -390,7 +395,8 @@ hipError_t distinct_from_plain(const uint8_t* d_plain, uint64_t plen, int k, int
         if (e == hipSuccess && acc_n) e = hipMemcpyAsync(cat_k.p, acc_k.p, 8 * acc_n, hipMemcpyDeviceToDevice, s);
         if (e == hipSuccess && acc_n) e = hipMemcpyAsync(cat_c.p, acc_c.p, 8 * acc_n, hipMemcpyDeviceToDevice, s);
         if (e == hipSuccess) e = hipMemcpyAsync((uint64_t*)cat_k.p + acc_n, pk, 8 * pm, hipMemcpyDeviceToDevice, s);
-        if (e == hipSuccess) { hipLaunchKernelGGL(k_widen_counts, dim3(grid_of(pm)), dim3(kB), 0, s, pc, pm, (uint64_t*)cat_c.p + acc_n); e = hipGetLastError(); }
+        if (e == hipSuccess && pc64) e = hipMemcpyAsync((uint64_t*)cat_c.p + acc_n, pc64, 8 * pm, hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess && !pc64) { hipLaunchKernelGGL(k_widen_counts, dim3(grid_of(pm)), dim3(kB), 0, s, pc, pm, (uint64_t*)cat_c.p + acc_n); e = hipGetLastError(); }
         if (e == hipSuccess && acc_n == 0) {                                  // first non-empty piece: already sorted and distinct
             (void)hipStreamSynchronize(s);
             acc_k.p = cat_k.release(); acc_c.p = cat_c.release(); acc_n = tot;
