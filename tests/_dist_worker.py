@@ -91,6 +91,24 @@ def main():
     assert adist.merge_scatter_shards(torch.zeros(orc.n, dtype=torch.int64), torch.zeros(orc.n, dtype=torch.int32), dup) is True
     t = adist.all_reduce_max_float(float(rank + 1))
     assert t == 2.0
+    # helpers of the device-resident shard protocols (positions_fill_sharded_t / scatter_sharded_t), on CPU tensors here: u32 bit
+    # patterns of tallies above 2^31, the rank-ordered gather that turns them into "occurrences in the shards before mine", the
+    # in-place reductions, and the collective error flag that makes every rank raise together
+    tall = torch.tensor([0, 5, (1 << 31) + 7, (1 << 32) - 1, (1 << 40)], dtype=torch.int64) + rank
+    bits = adist._u32_bits(tall)
+    assert bits.dtype == torch.int32 and (bits.to(torch.int64) & 0xFFFFFFFF).tolist() == [min(int(v), (1 << 32) - 1) for v in tall.tolist()]
+    parts = adist._all_gather(bits)
+    assert len(parts) == world and all((p_.to(torch.int64) & 0xFFFFFFFF).tolist() == [min(int(v) - rank + r, (1 << 32) - 1) for v in tall.tolist()] for r, p_ in enumerate(parts))
+    before = sum((p_.to(torch.int64) & 0xFFFFFFFF) for p_ in parts[:rank]) if rank else torch.zeros(5, dtype=torch.int64)
+    assert before.tolist() == ([0, 0, 0, 0, 0] if rank == 0 else [0, 5, (1 << 31) + 7, (1 << 32) - 1, (1 << 32) - 1])
+    x = torch.tensor([rank + 1, 10 * (rank + 1)], dtype=torch.int64)
+    assert adist._all_reduce_(x.clone(), "sum").tolist() == [3, 30] and adist._all_reduce_(x.clone(), "max").tolist() == [2, 20]
+    adist._raise_together(None, "nothing failed")
+    try:
+        adist._raise_together(RuntimeError("boom") if rank == 1 else None, "one rank failed")
+        raise AssertionError("no rank raised")
+    except RuntimeError as e:
+        assert ("boom" in str(e)) == (rank == 1) and "one rank failed" in str(e)
     adist.barrier()
     if rank == 0:
         print("DIST_OK")
