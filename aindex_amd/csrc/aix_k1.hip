@@ -198,9 +198,14 @@ __global__ void __launch_bounds__(K1_FB) k_k1_final(const uint32_t* __restrict__
             for (uint32_t i = t; i < m; i += K1_FB) {
                 const uint32_t key = dk[i];
                 uint32_t r = 0;
-                for (uint32_t j = 0; j < m; j += 4) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(&dk[j]);
-                    r += (v.x < key ? 1u : 0u) + (v.y < key ? 1u : 0u) + (v.z < key ? 1u : 0u) + (v.w < key ? 1u : 0u);
+                const uint32_t m16 = (m + 15u) & ~15u;                  // dk is +infinity past m (at least up to the next multiple of 16: K1_DMAX + 4 entries, m <= 384)
+                for (uint32_t j = 0; j < m16; j += 16) {                // four independent 16-byte reads in flight
+                    const uint4 v0 = *reinterpret_cast<const uint4*>(&dk[j]), v1 = *reinterpret_cast<const uint4*>(&dk[j + 4]);
+                    const uint4 v2 = *reinterpret_cast<const uint4*>(&dk[j + 8]), v3 = *reinterpret_cast<const uint4*>(&dk[j + 12]);
+                    r += (v0.x < key ? 1u : 0u) + (v0.y < key ? 1u : 0u) + (v0.z < key ? 1u : 0u) + (v0.w < key ? 1u : 0u);
+                    r += (v1.x < key ? 1u : 0u) + (v1.y < key ? 1u : 0u) + (v1.z < key ? 1u : 0u) + (v1.w < key ? 1u : 0u);
+                    r += (v2.x < key ? 1u : 0u) + (v2.y < key ? 1u : 0u) + (v2.z < key ? 1u : 0u) + (v2.w < key ? 1u : 0u);
+                    r += (v3.x < key ? 1u : 0u) + (v3.y < key ? 1u : 0u) + (v3.z < key ? 1u : 0u) + (v3.w < key ? 1u : 0u);
                 }
                 keys_out[lo + r] = prefix | key;
                 cnt_out[lo + r] = dc[i];
