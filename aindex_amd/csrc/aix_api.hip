@@ -76,7 +76,9 @@ struct aix_index {
     bool bk_lpp_set = false;                   // chosen by the caller (AIX_BUCKET_LANES / aix_index_set_bucket_table): then every consumer uses it
     uint64_t bk_unfiled = 0;                   // keys beyond the eighth of their bucket (answered through the MPHF)
     bool bk_enabled = true;
-    BkEntry* mk = nullptr;                     // minimizer-keyed copy of the table for the streaming counter (nbm buckets of 16 entries)
+    BkEntry* mk = nullptr;                     // minimizer-keyed copy of the table for the streaming counter: entries grouped by minimizer bucket
+    uint32_t* mk_off = nullptr;                // nbm + 1 offsets into mk
+    uint32_t mk_cap = 16;                      // entries of a bucket a lane of the streaming counter reads
     uint32_t nbm = 0;
     uint64_t mk_unfiled = 0;
     bool mk_enabled = true;
@@ -132,6 +134,8 @@ struct aix_index {
         d.nbloom = nbloom;
         d.mk = (d.bk && mk && mk_enabled) ? mk : nullptr;
         d.nbm = nbm;
+        d.mk_off = mk_off;
+        d.mk_cap = mk_cap;
         return d;
     }
 };
@@ -264,6 +268,7 @@ static void destroy(aix_index* h) {
     if (h->bk) (void)hipFree(h->bk);
     if (h->bloom) (void)hipFree(h->bloom);
     if (h->mk) (void)hipFree(h->mk);
+    if (h->mk_off) (void)hipFree(h->mk_off);
     if (h->tf13_mphf) (void)hipFree(h->tf13_mphf);
     if (h->tf13_code) (void)hipFree(h->tf13_code);
     if (h->perm13) (void)hipFree(h->perm13);
@@ -308,34 +313,45 @@ static int build_bucket_table(aix_index* h, hipStream_t s) {
         h->device_bytes += 8 * nw;
         HIPCHK(hipMemsetAsync(h->bloom, 0, 8 * nw, s));
     }
-    // minimizer-keyed copy for the streaming consumers (counting, coverage, positions): built only on request
-    // (AIX_MINIMIZER_TABLE=1). Measured and NOT adopted as the default: it does cut the HBM lines per window ~5x, but once a
-    // probe costs one line those kernels are bound by their instruction stream (encode + canonical form + hash / minimizer +
-    // compare: ~60 % of the VALU peak), and the minimizer walk costs more instructions than the Jenkins hash it replaces —
-    // count23 47.7 ms against 43.5 ms per 10 M reads, coverage 34.8 against 31.8 ms, positions 45.9 against 43.2 ms.
+    // minimizer-keyed copy for the streaming counter (aix_stream23.hip): built only on request (AIX_MINIMIZER_TABLE=1). Every filed key
+    // once more, grouped by the bucket of its minimizer (offsets + entries: a bucket is as long as its content, 16 B per key + 4 B per
+    // bucket); AIX_MINIMIZER_LOAD = mean keys per bucket (default 2: the offsets of 5e7 keys are 100 MB, Infinity-Cache sized).
     bool want_mk = false;
     if (const char* e = getenv("AIX_MINIMIZER_TABLE")) want_mk = atoi(e) != 0;
     uint64_t nbm = 0;
     if (want_mk) {
-        double mload = 6.0;                                                    // keys per 16-entry bucket of the minimizer-keyed copy (the groups of one minimizer arrive together)
-        if (const char* e = getenv("AIX_MINIMIZER_LOAD")) { const double v = atof(e); if (v >= 0.5 && v <= 16.0) mload = v; }
+        double mload = 2.0;
+        if (const char* e = getenv("AIX_MINIMIZER_LOAD")) { const double v = atof(e); if (v >= 0.25 && v <= 16.0) mload = v; }
         nbm = (uint64_t)((double)h->n / mload) + 1;
         if (nbm > 0xFFFFFFF0ull) nbm = 0xFFFFFFF0ull;
-        HIPCHK(hipMalloc((void**)&h->mk, nbm * AIX_MK_ENTRIES * sizeof(BkEntry)));
-        h->nbm = (uint32_t)nbm;
-        h->device_bytes += nbm * AIX_MK_ENTRIES * sizeof(BkEntry);
     }
     DevBuf mfill(s);
-    const uint64_t mfill_words = nbm + 1;
-    HIPCHK(mfill.alloc_once(4 * mfill_words + 8));
-    HIPCHK(hipMemsetAsync(mfill.p, 0, 4 * mfill_words + 8, s));
-    uint32_t* d_unfiled = (uint32_t*)mfill.p + mfill_words;
-    HIPCHK(launch_build_buckets(h->dev().m, h->keys, h->n, h->bk, h->nb, (uint32_t*)fill.p, h->bloom, h->nbloom, h->mk, h->nbm, (uint32_t*)mfill.p, d_unfiled, s));
-    {
-        uint32_t u = 0;
-        HIPCHK(hipMemcpyAsync(&u, d_unfiled, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(mfill.alloc_once(4 * (nbm + 1)));
+    HIPCHK(hipMemsetAsync(mfill.p, 0, 4 * (nbm + 1), s));
+    HIPCHK(launch_build_buckets(h->dev().m, h->keys, h->n, h->bk, h->nb, (uint32_t*)fill.p, h->bloom, h->nbloom, (uint32_t)nbm, (uint32_t*)mfill.p, s));
+    h->mk_cap = AIX_MK_ENTRIES;
+    if (const char* e = getenv("AIX_MINIMIZER_CAP")) { const int v = atoi(e); if (v >= 1 && v <= AIX_MK_ENTRIES) h->mk_cap = (uint32_t)v; }   // test hook: short buckets -> many undecided windows
+    if (want_mk) {
+        // offsets = exclusive scan of the bucket sizes (a bucket holds < 2^32 keys in total: n < 2^32), then the entries
+        HIPCHK(hipMalloc((void**)&h->mk_off, 4 * (nbm + 1)));
+        h->device_bytes += 4 * (nbm + 1);
+        HIPCHK(exclusive_scan_u32((const uint32_t*)mfill.p, h->mk_off, nbm + 1, s));
+        uint32_t filed = 0;
+        HIPCHK(hipMemcpyAsync(&filed, h->mk_off + nbm, 4, hipMemcpyDeviceToHost, s));
+        // keys the streaming counter cannot answer from their bucket (longer than the cap): host side, once per open
+        std::vector<uint32_t> mf;
+        try { mf.resize(nbm); } catch (const std::bad_alloc&) { return AIX_ERR_NOMEM; }
+        HIPCHK(hipMemcpyAsync(mf.data(), mfill.p, 4 * nbm, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        h->mk_unfiled = u;
+        uint64_t left = 0;
+        for (uint64_t i = 0; i < nbm; ++i) if (mf[i] > h->mk_cap) left += mf[i];
+        h->mk_unfiled = left;
+        HIPCHK(hipMalloc((void**)&h->mk, (uint64_t)(filed ? filed : 1) * sizeof(BkEntry)));
+        h->device_bytes += (uint64_t)filed * sizeof(BkEntry);
+        h->nbm = (uint32_t)nbm;
+        HIPCHK(hipMemsetAsync(mfill.p, 0, 4 * (nbm + 1), s));
+        HIPCHK(launch_fill_minimizer_table(h->dev().m, h->keys, h->n, h->mk, h->mk_off, h->nbm, (uint32_t*)mfill.p, s));
+        HIPCHK(hipStreamSynchronize(s));
     }
     // keys left to the MPHF path: sum over buckets of max(fill - 8, 0) (host side: once per open, nb words)
     std::vector<uint32_t> f;

@@ -488,10 +488,11 @@ __device__ __forceinline__ BkRes bucket_probe_wave(const BkEntry* __restrict__ b
 // Minimizer-keyed copy of the verification table, for the STREAMING counter (aix_stream23.hip: every window of a read).
 // Consecutive windows of a sequence share 22 bases and — about seven in a row — their minimizer (the 15-mer of the window with
 // the smallest hash, taken over both strands, so it is the same for a k-mer and its reverse complement). Filing a key under
-// its minimizer instead of its own hash sends those windows to the SAME bucket: one HBM read per super-k-mer instead of one
-// per window. A bucket is 16 entries = two 128-byte lines read together (the keys of one minimizer arrive in groups, so the
-// buckets fill unevenly); a key that finds its bucket full stays out and the bucket's last entry gets the overflow bit: a
-// probe that does not find its code in such a bucket is UNDECIDED and is settled by the MPHF path.
+// its minimizer instead of its own hash sends those windows to the SAME bucket: one read per super-k-mer instead of one per window.
+// The keys of one minimizer arrive together (~8 at a time), so fixed 16-entry buckets overflowed for 15-30 % of the windows; the
+// copy is therefore laid out by content: bucket b = entries [off[b], off[b + 1]) of one contiguous array, every filed key in it.
+// A lane reads at most AIX_MK_ENTRIES of a bucket into registers; a window whose (longer) bucket does not show its code is
+// UNDECIDED and is settled through the hash-keyed table inside the same kernel.
 // ---------------------------------------------------------------------------------------------
 #define AIX_MK_ENTRIES 16
 __device__ __forceinline__ uint32_t mmer_mix(uint32_t x) {        // a bijection of u32: equal hashes <=> equal 15-mers

@@ -24,8 +24,10 @@ struct IndexDev {
     uint32_t bk_lpp;          // lanes that share one bucket read (8, 4, 2 or 1); launch-time choice
     const uint64_t* bloom;    // 23-mer: absence filter in front of the table (nbloom 64-bit words), nullptr when off
     uint32_t nbloom;
-    const BkEntry* mk;        // 23-mer: minimizer-keyed copy of the table for the streaming counter (nbm buckets of AIX_MK_ENTRIES), nullptr when off
+    const BkEntry* mk;        // 23-mer: minimizer-keyed copy of the table for the streaming counter: the entries of bucket b are mk[mk_off[b] .. mk_off[b + 1]); nullptr when off
     uint32_t nbm;
+    const uint32_t* mk_off;   // nbm + 1 offsets into mk (a bucket = all filed keys whose minimizer hashes to it: no bucket overflows at build time)
+    uint32_t mk_cap;          // entries of a bucket a lane reads (<= AIX_MK_ENTRIES); a longer bucket leaves its windows to the hash-keyed table
 };
 
 enum LookupMode { MODE_TF = 0, MODE_HASH = 1, MODE_KIDSTRAND = 2, MODE_BOTH = 3, MODE_TOTAL = 4, MODE_LINES = 5 };
@@ -57,8 +59,9 @@ hipError_t launch_set_fingerprints(const MphfDev& m, BvRec* recs_rw, EeRec* ee_r
 // verification table: bk (nb * 8 entries) is initialised and filled from the keys that sit in their own MPHF slot;
 // fill = nb zeroed u32 counters (scratch)
 hipError_t launch_build_buckets(const MphfDev& m, const KeyRec* keys, uint64_t n, BkEntry* bk, uint32_t nb, uint32_t* fill, uint64_t* bloom /* zeroed, nullable */,
-                                uint32_t nbloom, BkEntry* mk /* nullable */, uint32_t nbm, uint32_t* mfill /* nbm zeroed words */,
-                                uint32_t* unfiled /* zeroed counter */, hipStream_t s);
+                                uint32_t nbloom, uint32_t nbm /* 0: no minimizer-keyed copy */, uint32_t* mfill /* nbm zeroed words: keys per minimizer bucket */, hipStream_t s);
+// second pass of the minimizer-keyed copy: entries written at mk[off[bucket] + arrival]; mcur = nbm zeroed words
+hipError_t launch_fill_minimizer_table(const MphfDev& m, const KeyRec* keys, uint64_t n, BkEntry* mk, const uint32_t* off, uint32_t nbm, uint32_t* mcur, hipStream_t s);
 hipError_t launch_scatter23(const MphfDev& m, uint64_t n, uint64_t nslots, const uint8_t* keys_ascii /* or */, const uint64_t* codes, const uint32_t* counts,
                             uint64_t* checker, uint32_t* tf, uint32_t* occupied_bits, uint32_t* conflict, hipStream_t s);
 hipError_t launch_perm13(const MphfDev& m, uint32_t* perm /* [4^13]: code -> mphf index */, hipStream_t s);
@@ -85,6 +88,9 @@ hipError_t launch_count23_fixed(const IndexDev& ix, const uint8_t* buf, uint64_t
 hipError_t launch_window_codes(const uint8_t* buf, uint64_t len, int k, int canon_mode, uint64_t* out /* [len-k+1] */, hipStream_t s);
 
 hipError_t launch_gather(const uint8_t* table, uint64_t n_elems, int elem_bytes, int unroll, uint64_t n_access, uint64_t seed, uint64_t* sink, hipStream_t s);
+
+// out[i] = in[0] + ... + in[i - 1] (device arrays of n words; synchronises the stream)
+hipError_t exclusive_scan_u32(const uint32_t* d_in, uint32_t* d_out, uint64_t n, hipStream_t s);
 
 // positions index (aix_positions.hip)
 hipError_t positions_indices(const IndexDev& ix, uint64_t* d_indices /* n+1 */, hipStream_t s);

@@ -523,8 +523,7 @@ __global__ void __launch_bounds__(kBlock) k_bk_init(BkEntry* __restrict__ bk, ui
     }
 }
 __global__ void __launch_bounds__(kBlock) k_bk_fill(const MphfDev m, const KeyRec* __restrict__ keys, uint64_t n, BkEntry* __restrict__ bk, uint32_t nb,
-                                                   uint32_t* __restrict__ fill, uint64_t* __restrict__ bloom, uint32_t nbloom, BkEntry* __restrict__ mk, uint32_t nbm,
-                                                   uint32_t* __restrict__ mfill, uint32_t* __restrict__ unfiled) {
+                                                   uint32_t* __restrict__ fill, uint64_t* __restrict__ bloom, uint32_t nbloom, uint32_t nbm, uint32_t* __restrict__ mfill) {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         const KeyRec kr = keys[i];
@@ -539,18 +538,27 @@ __global__ void __launch_bounds__(kBlock) k_bk_fill(const MphfDev m, const KeyRe
         BkEntry e;
         e.code_lo = (uint32_t)kr.code; e.code_hi = (uint32_t)(kr.code >> 32); e.tf = kr.tf; e.slot = (uint32_t)i;
         if (pos < 8u) bk[(uint64_t)bi * 8 + pos] = e;
-        if (mk) {                                               // the same entry under its minimizer (16-entry buckets)
-            const uint32_t home = mk_home(minimizer23(kr.code, revcomp(kr.code, 23)), nbm);
-            const uint32_t p2 = atomicAdd(&mfill[home], 1u);
-            if (p2 < (uint32_t)AIX_MK_ENTRIES) mk[(uint64_t)home * AIX_MK_ENTRIES + p2] = e;
-            else atomicAdd(unfiled, 1u);
-        }
+        if (nbm) atomicAdd(&mfill[mk_home(minimizer23(kr.code, revcomp(kr.code, 23)), nbm)], 1u);    // the minimizer-keyed copy: sized here, written by k_mk_fill
     }
 }
-__global__ void __launch_bounds__(kBlock) k_mk_flag(BkEntry* __restrict__ mk, uint32_t nbm, const uint32_t* __restrict__ mfill) {
+// The same entries once more, grouped by the bucket of their minimizer: bucket b = mk[off[b], off[b + 1]) holds EVERY filed key whose
+// minimizer hashes to b (the keys of one minimizer arrive together, ~8 at a time, so fixed-size buckets overflowed for 15-30 % of the
+// windows; a bucket sized by its content never does). Same filing condition as k_bk_fill.
+__global__ void __launch_bounds__(kBlock) k_mk_fill(const MphfDev m, const KeyRec* __restrict__ keys, uint64_t n, BkEntry* __restrict__ mk, const uint32_t* __restrict__ off,
+                                                   uint32_t nbm, uint32_t* __restrict__ mcur) {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t bi = (uint64_t)blockIdx.x * kBlock + threadIdx.x; bi < nbm; bi += stride)
-        if (mfill[bi] > (uint32_t)AIX_MK_ENTRIES) mk[bi * AIX_MK_ENTRIES + AIX_MK_ENTRIES - 1].code_hi |= AIX_BK_OVERFLOW;   // keys were left out
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const KeyRec kr = keys[i];
+        if (kr.code >> 46) continue;
+        uint64_t w0, w1, w2, a, b, c;
+        ascii23_of_rc(revcomp(kr.code, 23), w0, w1, w2);
+        jenkins23(w0, w1, w2, m.seed, a, b, c);
+        if (mphf_from_hash(m, a, b, c) != i) continue;
+        const uint32_t home = mk_home(minimizer23(kr.code, revcomp(kr.code, 23)), nbm);
+        BkEntry e;
+        e.code_lo = (uint32_t)kr.code; e.code_hi = (uint32_t)(kr.code >> 32); e.tf = kr.tf; e.slot = (uint32_t)i;
+        mk[(uint64_t)off[home] + atomicAdd(&mcur[home], 1u)] = e;
+    }
 }
 __global__ void __launch_bounds__(kBlock) k_bk_flag(BkEntry* __restrict__ bk, uint32_t nb, const uint32_t* __restrict__ fill) {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
@@ -943,14 +951,16 @@ hipError_t launch_set_fingerprints(const MphfDev& m, BvRec* recs_rw, EeRec* ee_r
     hipLaunchKernelGGL(k_init_ee, dim3(grid_for(m.nrecs)), dim3(kBlock), 0, s, (const BvRec*)recs_rw, m.nrecs, ee_rw);
     AIX_LAUNCH(k_set_fp, n, s, m, recs_rw, ee_rw, keys, n);
 }
-hipError_t launch_build_buckets(const MphfDev& m, const KeyRec* keys, uint64_t n, BkEntry* bk, uint32_t nb, uint32_t* fill, uint64_t* bloom, uint32_t nbloom, BkEntry* mk,
-                                uint32_t nbm, uint32_t* mfill, uint32_t* unfiled, hipStream_t s) {
+hipError_t launch_build_buckets(const MphfDev& m, const KeyRec* keys, uint64_t n, BkEntry* bk, uint32_t nb, uint32_t* fill, uint64_t* bloom, uint32_t nbloom, uint32_t nbm,
+                                uint32_t* mfill, hipStream_t s) {
     if (n == 0 || nb == 0) return hipSuccess;
     hipLaunchKernelGGL(k_bk_init, dim3(grid_for((uint64_t)nb * 8)), dim3(kBlock), 0, s, bk, (uint64_t)nb * 8);
-    if (mk) hipLaunchKernelGGL(k_bk_init, dim3(grid_for((uint64_t)nbm * AIX_MK_ENTRIES)), dim3(kBlock), 0, s, mk, (uint64_t)nbm * AIX_MK_ENTRIES);
-    hipLaunchKernelGGL(k_bk_fill, dim3(grid_for(n)), dim3(kBlock), 0, s, m, keys, n, bk, nb, fill, bloom, nbloom, mk, nbm, mfill, unfiled);
-    if (mk) hipLaunchKernelGGL(k_mk_flag, dim3(grid_for(nbm)), dim3(kBlock), 0, s, mk, nbm, (const uint32_t*)mfill);
+    hipLaunchKernelGGL(k_bk_fill, dim3(grid_for(n)), dim3(kBlock), 0, s, m, keys, n, bk, nb, fill, bloom, nbloom, nbm, mfill);
     AIX_LAUNCH(k_bk_flag, nb, s, bk, nb, (const uint32_t*)fill);
+}
+hipError_t launch_fill_minimizer_table(const MphfDev& m, const KeyRec* keys, uint64_t n, BkEntry* mk, const uint32_t* off, uint32_t nbm, uint32_t* mcur, hipStream_t s) {
+    if (n == 0 || nbm == 0) return hipSuccess;
+    AIX_LAUNCH(k_mk_fill, n, s, m, keys, n, mk, off, nbm, mcur);
 }
 hipError_t launch_scatter23(const MphfDev& m, uint64_t n, uint64_t nslots, const uint8_t* keys, const uint64_t* codes, const uint32_t* counts, uint64_t* checker, uint32_t* tf,
                             uint32_t* occupied, uint32_t* conflict, hipStream_t s) {

@@ -149,6 +149,18 @@ static void launch_a2_probe(const IndexDev& ix, const uint8_t* d_reads, uint64_t
     else hipLaunchKernelGGL(k_a2_probe, dim3(grid_of(nwin)), dim3(kB), 0, s, ix, d_reads, nwin, start, keys);
 }
 
+hipError_t exclusive_scan_u32(const uint32_t* d_in, uint32_t* d_out, uint64_t n, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    size_t tb = 0;
+    hipError_t e = rocprim::exclusive_scan(nullptr, tb, d_in, d_out, 0u, (size_t)n, rocprim::plus<uint32_t>(), s);
+    void* tmp = nullptr;
+    if (e == hipSuccess) e = pool_alloc(&tmp, tb ? tb : 1);
+    if (e == hipSuccess) e = rocprim::exclusive_scan(tmp, tb, d_in, d_out, 0u, (size_t)n, rocprim::plus<uint32_t>(), s);
+    { const hipError_t es = hipStreamSynchronize(s); if (e == hipSuccess) e = es; }
+    if (tmp) pool_free(tmp);
+    return e;
+}
+
 // indices (device, n+1 entries). Returns hip error.
 hipError_t positions_indices(const IndexDev& ix, uint64_t* d_indices, hipStream_t s) {
     const uint64_t n = ix.n;

@@ -10,11 +10,12 @@
 //     code is a funnel shift of that stream;
 //   * the minimizer (smallest hash among the nine canonical 15-mers of the window) is kept incrementally: one new 15-mer hash
 //     per window, minimum over a ring of nine;
-//   * about seven windows in a row share a minimizer, hence their bucket of the table: the bucket (16 entries, two lines) stays
-//     in the lane's registers and is re-read only when the minimizer changes — one HBM read per super-k-mer, no hash of the
-//     k-mer at all.
-// A window the table cannot decide (its bucket carries the overflow bit and does not hold the code) is written as UNDECIDED
-// and settled afterwards by k_fix23 through the MPHF path, so the result is exactly that of k_probe23_slots.
+//   * about seven windows in a row share a minimizer, hence their bucket of the table: the bucket (its first 16 entries) stays in
+//     the lane's registers and is re-read only when the minimizer changes — one offsets read and one contiguous entry read per
+//     super-k-mer, no hash of the k-mer at all.
+// A window the bucket cannot decide (the bucket is longer than what a lane reads and does not show the code) is settled in the
+// same kernel through the hash-keyed verification table (one wave-cooperative line read for the lanes that need it), so the
+// result is exactly that of k_probe23_slots; k_fix23 remains only for a handle whose hash-keyed table is switched off.
 #include "aix_internal.hpp"
 
 namespace aix {
@@ -24,6 +25,13 @@ static constexpr int S23_ND = 14;                     // aligned dwords that cov
 static constexpr int S23_TB = 256;
 static constexpr uint32_t S23_NONE = 0xFFFFFFFFu;     // no k-mer / not a key
 static constexpr uint32_t S23_UND = 0xFFFFFFFEu;      // the table could not decide
+
+// every 'U' byte of an upper-cased word becomes 'T' (count_kmers.cpp:71-88 maps U/u to 3)
+__device__ __forceinline__ uint64_t s23_u_to_t(uint64_t x) {
+    const uint64_t z = x ^ 0x5555555555555555ULL;
+    const uint64_t nz = (((z & 0x7F7F7F7F7F7F7F7FULL) + 0x7F7F7F7F7F7F7F7FULL) | z) & 0x8080808080808080ULL;
+    return x ^ ((~nz & 0x8080808080808080ULL) >> 7);
+}
 
 struct Run23 {
     uint64_t hi, lo;      // 2-bit stream of bases 0..55, base 0 in the top two bits of hi
@@ -91,25 +99,30 @@ __device__ __forceinline__ uint32_t mmer_hash_at(const Run23& r) {
 struct BucketRegs {
     uint4 e[AIX_MK_ENTRIES];
 };
-__device__ __forceinline__ void load_bucket(const BkEntry* __restrict__ tab, uint32_t b, BucketRegs& L) {
-    const uint4* p = (const uint4*)(tab + (uint64_t)b * AIX_MK_ENTRIES);
+// bucket b of the minimizer-keyed copy = entries [off[b], off[b + 1]): the first `cap` (<= 16) of them into registers, the rest of the
+// registers empty. Returns true when the bucket is longer than that (its windows are left to the hash-keyed table).
+__device__ __forceinline__ bool load_bucket(const BkEntry* __restrict__ tab, const uint32_t* __restrict__ off, uint32_t b, uint32_t cap, BucketRegs& L) {
+    const uint32_t o0 = off[b], cnt = off[b + 1] - o0;
+    const uint4* p = (const uint4*)(tab + o0);
 #pragma unroll
-    for (int t = 0; t < AIX_MK_ENTRIES; ++t) L.e[t] = p[t];      // two 128-byte lines, sixteen independent loads in flight
+    for (int t = 0; t < AIX_MK_ENTRIES; ++t)                     // up to sixteen independent loads in flight; the bucket is contiguous
+        L.e[t] = (uint32_t)t < min(cnt, cap) ? p[t] : make_uint4(0xFFFFFFFFu, AIX_BK_EMPTY_HI, 0u, 0u);
+    return cnt > cap;
 }
-// compare `code` with the sixteen entries: the slot (or NONE); ovf = keys of this bucket were left out
-__device__ __forceinline__ uint32_t scan_bucket(const BucketRegs& L, uint64_t code, bool& ovf) {
+// compare `code` with the sixteen entries: the slot (or NONE)
+__device__ __forceinline__ uint32_t scan_bucket(const BucketRegs& L, uint64_t code) {
     const uint32_t lo = (uint32_t)code, hi = (uint32_t)(code >> 32);
     uint32_t slot = S23_NONE;
 #pragma unroll
     for (int t = 0; t < AIX_MK_ENTRIES; ++t)
         if (L.e[t].x == lo && (L.e[t].y & AIX_BK_HI_MASK) == hi) slot = L.e[t].w;
-    ovf = (L.e[AIX_MK_ENTRIES - 1].y & AIX_BK_OVERFLOW) != 0;
     return slot;
 }
 
 struct StreamState {
     uint32_t mh[9];       // ring: hashes of the nine canonical 15-mers of the current window (position p lives in mh[p % 9])
     uint32_t cur;         // bucket held in `regs`
+    bool long_bucket;     // ... of which only the first mk_cap entries: a code it does not show is UNDECIDED, not absent
     BucketRegs regs;
 };
 
@@ -135,11 +148,10 @@ __device__ __forceinline__ void stream_steps(const IndexDev& ix, const Run23& ru
             if (x < code) { key = x; mz = minimizer23(x, revcomp(x, 23)); }          // kmer_counter's pseudo-complement is no strand of the window: its own minimizer
         }
         const uint32_t home = mk_home(mz, ix.nbm);
-        if (want && home != st.cur) { load_bucket(ix.mk, home, st.regs); st.cur = home; }   // ~ once per seven windows
+        if (want && home != st.cur) { st.long_bucket = load_bucket(ix.mk, ix.mk_off, home, ix.mk_cap, st.regs); st.cur = home; }   // ~ once per seven windows
         if (want) {
-            bool ovf;
-            const uint32_t s = scan_bucket(st.regs, key, ovf);
-            slot = s != S23_NONE ? s : (ovf ? S23_UND : S23_NONE);
+            const uint32_t s = scan_bucket(st.regs, key);
+            slot = s != S23_NONE ? s : (st.long_bucket ? S23_UND : S23_NONE);
         }
         tr[J] = slot;
         stream_steps<J + 1>(ix, run, valid, canon_mode, st, tr);
@@ -159,6 +171,7 @@ __global__ void __launch_bounds__(S23_TB) k_stream23_slots(const IndexDev ix, co
     const uint32_t valid = (uint32_t)(m16 & (m4 >> 16) & (m2 >> 20) & (m >> 22));
     StreamState st;
     st.cur = AIX_BK_NONE;
+    st.long_bucket = false;
 #pragma unroll
     for (int t = 0; t < AIX_MK_ENTRIES; ++t) st.regs.e[t] = make_uint4(0xFFFFFFFFu, AIX_BK_EMPTY_HI, 0u, 0u);
     st.mh[0] = mmer_hash_at<0>(run); st.mh[1] = mmer_hash_at<1>(run); st.mh[2] = mmer_hash_at<2>(run);
@@ -170,14 +183,39 @@ __global__ void __launch_bounds__(S23_TB) k_stream23_slots(const IndexDev ix, co
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     bool und = false;
-#pragma unroll 4
+#pragma unroll 2
     for (int i = 0; i < S23_W; ++i) {
         const uint32_t idx = (uint32_t)i * 64u + lane;                               // position inside the wave's span
-        const uint32_t v = tr[wave][(idx >> 5) * (S23_W + 1) + (idx & 31u)];
+        uint32_t v = tr[wave][(idx >> 5) * (S23_W + 1) + (idx & 31u)];
         const uint64_t p = wave_first + idx;
+        // A window its minimizer bucket could not decide (the bucket overflowed when the table was built: a few per cent) is settled
+        // right here through the hash-keyed verification table — one wave-cooperative line read for the lanes that need it, the
+        // MPHF only behind an overflowed hash bucket — instead of a second pass over the whole slot stream (k_fix23)
+        const bool need = p < nwin && v == S23_UND && ix.bk != nullptr;
+        if (__ballot(need) != 0ull) {                                                 // uniform
+            uint64_t w0 = 0, w1 = 0, w2 = 0;
+            if (need) load23(buf + p, w0, w1, w2);
+            w0 = s23_u_to_t(w0 & 0xDFDFDFDFDFDFDFDFULL);
+            w1 = s23_u_to_t(w1 & 0xDFDFDFDFDFDFDFDFULL);
+            w2 = s23_u_to_t(w2 & 0x00DFDFDFDFDFDFDFULL);
+            const Enc23 e = encode23_words(w0, w1, w2);
+            uint64_t key = e.code;
+            if (canon_mode == 1) { const uint64_t x = revcomp_refx86(e.code, 23); key = e.code < x ? e.code : x; }
+            else if (canon_mode == 2) { const uint64_t x = revcomp(e.code, 23); key = e.code < x ? e.code : x; }
+            uint64_t s0, s1, s2, a, b, c;
+            ascii23_of_rc(revcomp(key, 23), s0, s1, s2);
+            jenkins23(s0, s1, s2, ix.m.seed, a, b, c);
+            const BkRes k = bucket_probe_wave<8>(ix.bk, ix.nb, need, a, key);
+            if (need) {
+                uint32_t slot = S23_NONE;
+                if (k.found) slot = k.slot;
+                else if (k.overflow) { const uint64_t h = mphf_from_hash(ix.m, a, b, c); if (h < ix.n && ix.keys[h].code == key) slot = (uint32_t)h; }
+                v = slot;
+            }
+        }
         if (p < nwin) { slots[p] = v; und = und || v == S23_UND; }
     }
-    if (__ballot(und) != 0ull && lane == 0) *any_undecided = 1u;                      // k_fix23 has something to do
+    if (__ballot(und) != 0ull && lane == 0) *any_undecided = 1u;                      // without the verification table: k_fix23 has something to do
 }
 
 // windows the table left UNDECIDED: the MPHF path, lane by lane (rare)

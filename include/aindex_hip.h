@@ -115,12 +115,12 @@ int aix_index_set_bucket_table(aix_index_t* h, int enabled, int lanes);
  * 8-byte read that answers most absent keys before the table is touched (AIX_BLOOM_BITS bits per key at open, default 16,
  * 0 = none). Off / on for A/B measurements; answers are identical. */
 int aix_index_set_absence_filter(aix_index_t* h, int enabled);
-/* Minimizer-keyed copy of the verification table, used by the STREAMING consumers (aix_count23_fixed*, aix_coverage_batch*,
- * aix_positions_*): every key is also filed under the minimizer of its 23-mer (the 15-mer with the smallest hash over both
- * strands), so the ~7 consecutive windows of a sequence that share a minimizer read the SAME 128-byte line — one HBM line
- * per super-k-mer instead of one per window. EXPERIMENTAL: built at open only with AIX_MINIMIZER_TABLE=1 (measured slower than
- * the hash-keyed table on MI355X: those kernels are instruction-bound once a probe costs one line); off / on per
- * handle for A/B measurements; answers are identical (verification in the line; undecided probes fall back to the hash-keyed table). */
+/* Minimizer-keyed copy of the verification table, used by the streaming form of aix_count23_fixed*: every filed key once more,
+ * grouped by the bucket of the minimizer of its 23-mer (the 15-mer with the smallest hash over both strands; offsets + entries,
+ * 16 B per key + 4 B per bucket), so the ~7 consecutive windows of a read that share a minimizer read ONE bucket. EXPERIMENTAL:
+ * built at open only with AIX_MINIMIZER_TABLE=1 (AIX_MINIMIZER_LOAD = mean keys per bucket, default 2); measured 6-12 % faster than
+ * the hash-keyed probe at one key per bucket and slower at four, so it is not the default; off / on per handle for
+ * A/B measurements; answers are identical (verification in the bucket; undecided windows are settled through the hash-keyed table). */
 int aix_index_set_minimizer_table(aix_index_t* h, int enabled);
 /* replace the tf table of a 13-mer handle (u64[4^13], mphf order, HOST pointer) */
 int aix_index_set_tf_13(aix_index_t* h, const uint64_t* tf);

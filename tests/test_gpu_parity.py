@@ -1413,11 +1413,14 @@ def test_count23_histogram_backend_equals_atomics_and_oracle(canon_case, small23
     monkeypatch.setenv("AIX_MINIMIZER_TABLE", "1")                          # the minimizer-keyed copy + streaming probe kernel (experimental) are built
     prefix = canon_case["prefix"]
     with Index.open_23(small23_prefix + ".pf", small23_prefix + ".tf.bin", small23_prefix + ".kmers.bin") as gix:
-        monkeypatch.setenv("AIX_MINIMIZER_LOAD", "14")                      # 14 keys per 16-entry bucket: many buckets overflow, k_fix23 settles those windows
+        monkeypatch.setenv("AIX_MINIMIZER_LOAD", "14")                      # 14 keys per bucket on average: many buckets are longer than the 16 entries a lane reads, those windows go through the hash-keyed table
         cix = Index.open_23(prefix + ".pf", prefix + ".tf.bin", prefix + ".kmers.bin")
         monkeypatch.delenv("AIX_MINIMIZER_LOAD")
-        assert cix.info["minimizer_unfiled_keys"] > 0 and gix.info["minimizer_lines"] > 0
-        cases = [(cix, orc, reads), (cix, orc, noisy), (gix, O.OracleIndex23.from_prefix(small23_prefix), gold_reads)]
+        monkeypatch.setenv("AIX_MINIMIZER_CAP", "3")                        # a lane reads three entries of a bucket: nearly every window is settled by the hash-keyed table
+        tix = Index.open_23(prefix + ".pf", prefix + ".tf.bin", prefix + ".kmers.bin")
+        monkeypatch.delenv("AIX_MINIMIZER_CAP")
+        assert cix.info["minimizer_unfiled_keys"] > 0 and gix.info["minimizer_lines"] > 0 and tix.info["minimizer_unfiled_keys"] > cix.n // 4
+        cases = [(cix, orc, reads), (cix, orc, noisy), (tix, orc, noisy), (gix, O.OracleIndex23.from_prefix(small23_prefix), gold_reads)]
         for ix, o, buf in cases:
             for mode in (0, 1, 2):
                 want = o.count23_fixed(buf, False, mode)
@@ -1445,6 +1448,7 @@ def test_count23_histogram_backend_equals_atomics_and_oracle(canon_case, small23
                 assert np.array_equal(acc.cpu().numpy().view(np.uint32), 2 * want)
                 monkeypatch.delenv("AIX_COUNT23_HIST_MIN")
         cix.close()
+        tix.close()
 
 
 def test_bucket_table_every_consumer_on_off_and_overflowing(canon_case, small23_prefix, monkeypatch):
