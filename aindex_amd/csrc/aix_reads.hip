@@ -1,0 +1,169 @@
+// aix_reads.hip — N4 row, host side: the step before counting (src/compute_reads.cpp:20-216). FASTQ (paired or single), FASTA or a
+// plain reads file -> <prefix>.reads (one record per line; a pair as R1~revcomp(R2)), <prefix>.ridx ("rid\tstart\tend" per record) and,
+// for FASTA, <prefix>.header ("name\tstart\tlength"). Text reformatting bound by file I/O: no device work, no GPU needed; the inputs are
+// memory-mapped and walked once, the outputs leave through large buffers. Line rules are std::getline's: lines end at '\n', a final
+// line without one still counts, no line follows a trailing '\n'.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/aindex_hip.h"
+
+namespace {
+
+struct Mapped {                                   // a whole file, read-only
+    const char* p = nullptr;
+    size_t n = 0;
+    bool open(const char* path) {
+        const int fd = ::open(path, O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0) { ::close(fd); return false; }
+        n = (size_t)st.st_size;
+        if (n) {
+            void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m == MAP_FAILED) { ::close(fd); n = 0; return false; }
+            (void)madvise(m, n, MADV_SEQUENTIAL);
+            p = (const char*)m;
+        }
+        ::close(fd);
+        return true;
+    }
+    ~Mapped() { if (p) munmap((void*)p, n); }
+};
+
+struct Line { const char* s = ""; size_t len = 0; };          // a std::string variable of the reference's loops, as a view into the mapped file
+
+// std::getline on one input file, including what it does to its string argument when it FAILS, because the reference's loops go on
+// using the variable: the first failing call on a stream that is still good() (everything consumed, the file ended with '\n' or is
+// empty) erases the string; once eofbit is set — the last line had no '\n' — or after a failure, the string is left as it was.
+struct Lines {
+    const char *cur, *end;
+    bool eofbit = false, failed = false;
+    explicit Lines(const Mapped& m) : cur(m.p), end(m.p + m.n) {}
+    bool getline(Line& v) {
+        if (!eofbit && !failed && cur != nullptr && cur < end) {
+            const char* nl = (const char*)memchr(cur, '\n', (size_t)(end - cur));
+            v.s = cur;
+            v.len = nl ? (size_t)(nl - cur) : (size_t)(end - cur);
+            cur = nl ? nl + 1 : end;
+            if (!nl) eofbit = true;                // the delimiter was the end of the file
+            return true;
+        }
+        if (!eofbit && !failed) { v.s = ""; v.len = 0; }          // good() stream, nothing left: erased, then eofbit | failbit
+        eofbit = failed = true;
+        return false;
+    }
+};
+
+struct Out {                                      // buffered writer; `bad` is sticky
+    FILE* f = nullptr;
+    std::string buf;
+    bool bad = false;
+    bool open(const std::string& path) { f = fopen(path.c_str(), "wb"); buf.reserve(1u << 23); return f != nullptr; }
+    void flush() { if (f && !buf.empty()) { if (fwrite(buf.data(), 1, buf.size(), f) != buf.size()) bad = true; buf.clear(); } }
+    void put(const char* s, size_t n) { buf.append(s, n); if (buf.size() >= (1u << 23) - 4096) flush(); }
+    void put(char c) { buf.push_back(c); }
+    void num(uint64_t v) { char t[24]; int i = 24; do { t[--i] = (char)('0' + v % 10); v /= 10; } while (v); buf.append(t + i, (size_t)(24 - i)); }
+    bool close() { flush(); if (f) { if (fclose(f) != 0) bad = true; f = nullptr; } return !bad; }
+    ~Out() { if (f) fclose(f); }
+};
+
+// get_revcomp(const std::string&) of the reference (kmers.cpp:310-330): reversed, A<->T, C<->G, anything else 'N'
+void put_revcomp(Out& o, const char* s, size_t n) {
+    static const struct Tab { char t[256]; Tab() { memset(t, 'N', sizeof t); t[(unsigned char)'A'] = 'T'; t[(unsigned char)'C'] = 'G'; t[(unsigned char)'G'] = 'C'; t[(unsigned char)'T'] = 'A'; } } tab;
+    char tmp[4096];
+    while (n) {
+        const size_t m = n < sizeof tmp ? n : sizeof tmp;
+        for (size_t i = 0; i < m; ++i) tmp[i] = tab.t[(unsigned char)s[n - 1 - i]];
+        o.put(tmp, m);
+        n -= m;
+    }
+}
+
+void ridx_line(Out& o, uint64_t rid, uint64_t start, uint64_t end) {
+    o.num(rid); o.put('\t'); o.num(start); o.put('\t'); o.num(end); o.put('\n');
+    if (o.buf.size() >= (1u << 22)) o.flush();
+}
+
+}  // namespace
+
+extern "C" int aix_compute_reads(const char* file1, const char* file2, const char* mode, const char* prefix) {
+    if (!file1 || !mode || !prefix) return AIX_ERR_ARG;
+    const std::string m(mode), pre(prefix);
+    const bool pe = m == "fastq", se = m == "se", plain = m == "reads", fasta = m == "fasta";
+    if (!pe && !se && !plain && !fasta) return AIX_ERR_ARG;
+    Mapped a, b;
+    if (!a.open(file1)) return AIX_ERR_IO;
+    if (pe && (!file2 || !b.open(file2))) return AIX_ERR_IO;
+    Out reads, ridx, header;
+    if (!plain && !reads.open(pre + ".reads")) return AIX_ERR_IO;
+    if (!ridx.open(pre + ".ridx")) return AIX_ERR_IO;
+    if (fasta && !header.open(pre + ".header")) return AIX_ERR_IO;
+    uint64_t n = 0, start = 0;
+    Line line1, line2;                            // the reference's two std::string variables
+    if (pe) {                                     // :77-116: four lines per record in both files, the second one is the sequence
+        Lines A(a), B(b);
+        while (A.getline(line1)) {
+            A.getline(line1);
+            B.getline(line2);
+            B.getline(line2);
+            const uint64_t end = start + line1.len + line2.len + 1;      // + the '~' between the mates
+            reads.put(line1.s, line1.len); reads.put('~'); put_revcomp(reads, line2.s, line2.len); reads.put('\n');
+            ridx_line(ridx, n, start, end);
+            start = end + 1;                                              // + the newline
+            ++n;
+            A.getline(line1); A.getline(line1); B.getline(line2); B.getline(line2);
+        }
+    } else if (se) {                              // :118-147
+        Lines A(a);
+        while (A.getline(line1)) {
+            A.getline(line1);
+            const uint64_t end = start + line1.len;
+            reads.put(line1.s, line1.len); reads.put('\n');
+            ridx_line(ridx, n, start, end);
+            start = end + 1;
+            ++n;
+            A.getline(line1); A.getline(line1);
+        }
+    } else if (plain) {                           // :149-168: the index of a reads file that exists already
+        Lines A(a);
+        while (A.getline(line1)) {
+            const uint64_t end = start + line1.len;
+            ridx_line(ridx, n, start, end);
+            start = end + 1;
+            ++n;
+        }
+    } else {                                      // :170-213: a record = the lines between two '>' lines, joined
+        Lines A(a);
+        std::string name;
+        uint64_t cur = 0;                         // length of the sequence gathered so far (its bytes are in `reads` already)
+        auto finish = [&]() {
+            const uint64_t end = start + cur;
+            reads.put('\n');
+            ridx_line(ridx, n, start, end);
+            header.put(name.data(), name.size()); header.put('\t'); header.num(start); header.put('\t'); header.num(cur); header.put('\n');
+            if (header.buf.size() >= (1u << 22)) header.flush();
+            start = end + 1;
+            ++n;
+            cur = 0;
+        };
+        while (A.getline(line1)) {
+            if (line1.len && line1.s[0] == '>') {  // (an empty line is no header: the reference reads its terminating NUL there)
+                if (cur) finish();
+                name.assign(line1.s + 1, line1.len - 1);
+                continue;
+            }
+            reads.put(line1.s, line1.len);
+            cur += line1.len;
+        }
+        if (cur) finish();
+    }
+    const bool ok_reads = plain || reads.close(), ok_ridx = ridx.close(), ok_header = !fasta || header.close();      // every file is closed
+    return ok_reads && ok_ridx && ok_header ? AIX_OK : AIX_ERR_IO;
+}

@@ -102,95 +102,25 @@ def compute_index(argv) -> int:
 
 def compute_reads(argv) -> int:
     """compute_reads.cpp:20-216: <file1> <file2|-> <fastq|fasta|se|reads> <output_prefix> -> .reads / .ridx / .header.
-    Host-side text reformatting exactly as the reference (I/O bound; no device work)."""
+    Text reformatting bound by file I/O: done by the library's host routine aix_compute_reads (memory-mapped input, one pass,
+    no device work: runs without a GPU)."""
     if len(argv) < 4:
         print("Expected arguments: compute_reads <fastq_file1|fasta_file1|reads_file> <fastq_file2|-> <fastq|fasta|se|reads> <output_prefix>",
               file=sys.stderr)
         return 1
     f1, f2, mode, prefix = argv[:4]
     import os
+    from ._lib import lib, AIX_ERR_ARG
     d = os.path.dirname(prefix)
     if d:
         os.makedirs(d, exist_ok=True)
-
-    def lines(path):
-        data = open(path, "rb").read()
-        out = data.split(b"\n")
-        if out and out[-1] == b"":
-            out.pop()                      # std::getline yields no empty line after a trailing newline
-        return out
-
-    comp = bytes.maketrans(b"ACGT", b"TGCA")
-
-    def revcomp(s: bytes) -> bytes:        # get_revcomp(const std::string&), kmers.cpp:310-330: others -> 'N'
-        return bytes(c if c in b"ACGT" else 78 for c in s[::-1]).translate(comp)
-
-    reads, ridx, header = [], [], []
-    start = 0
-    n = 0
-    if mode == "fastq":                    # :77-116 R1~revcomp(R2)
-        a, b = lines(f1), lines(f2)
-        i = 0
-        while i < len(a):                  # while getline(fin1) [header] ; then sequence lines, then 2 more lines each
-            l1 = a[i + 1] if i + 1 < len(a) else b""
-            l2 = b[i + 1] if i + 1 < len(b) else b""
-            end = start + len(l1) + len(l2) + 1
-            reads.append(l1 + b"~" + revcomp(l2) + b"\n")
-            ridx.append(b"%d\t%d\t%d\n" % (n, start, end))
-            start = end + 1
-            n += 1
-            i += 4
-    elif mode == "se":                     # :118-147
-        a = lines(f1)
-        i = 0
-        while i < len(a):
-            l1 = a[i + 1] if i + 1 < len(a) else b""
-            end = start + len(l1)
-            reads.append(l1 + b"\n")
-            ridx.append(b"%d\t%d\t%d\n" % (n, start, end))
-            start = end + 1
-            n += 1
-            i += 4
-    elif mode == "reads":                  # :149-168: index only
-        for l1 in lines(f1):
-            end = start + len(l1)
-            ridx.append(b"%d\t%d\t%d\n" % (n, start, end))
-            start = end + 1
-            n += 1
-        reads = None
-    elif mode == "fasta":                  # :170-213
-        cur, head = b"", b""
-
-        def flush():
-            nonlocal start, n, cur
-            end = start + len(cur)
-            reads.append(cur + b"\n")
-            ridx.append(b"%d\t%d\t%d\n" % (n, start, end))
-            header.append(head + b"\t%d\t%d\n" % (start, len(cur)))
-            start = end + 1
-            n += 1
-            cur = b""
-
-        for l1 in lines(f1):
-            if l1[:1] == b">":             # line1[0] == '>' (an empty line reads the terminating NUL: not '>')
-                if cur:
-                    flush()
-                head = l1[1:]
-                continue
-            cur += l1
-        if cur:
-            flush()
-    else:
+    st = lib().aix_compute_reads(f1.encode(), f2.encode() if mode == "fastq" else None, mode.encode(), prefix.encode())
+    if st == AIX_ERR_ARG:
         print("Unknown format.", file=sys.stderr)
         return 2
-    if reads is not None:
-        with open(prefix + ".reads", "wb") as f:
-            f.write(b"".join(reads))
-    with open(prefix + ".ridx", "wb") as f:
-        f.write(b"".join(ridx))
-    if mode == "fasta":
-        with open(prefix + ".header", "wb") as f:
-            f.write(b"".join(header))
+    if st != 0:
+        print(f"compute_reads: cannot read {f1}" + (f" / {f2}" if mode == "fastq" else "") + f" or write {prefix}.*", file=sys.stderr)
+        return 10
     return 0
 
 

@@ -298,6 +298,12 @@ void aix_distinct_free(aix_distinct_t* r);
  * fasta_mode: 0 = count_kmers13 rules, 1 = kmer_counter rules ('>' anywhere starts a record). */
 int aix_normalize_reads(const char* buf, uint64_t len, int format, int fasta_mode, char* out, uint64_t* out_len);
 int aix_detect_format(const char* buf, uint64_t len);  /* count_kmers13.cpp:194-206 */
+/* Replaces the binary `compute_reads <file1> <file2|-> <fastq|fasta|se|reads> <prefix>` (src/compute_reads.cpp:20-216), host side (text
+ * reformatting bound by file I/O: no device work, runs without a GPU): writes <prefix>.reads (a pair as R1~revcomp(R2), revcomp =
+ * get_revcomp of kmers.cpp:310-330: anything but ACGT becomes N), <prefix>.ridx ("rid\tstart\tend") and, for FASTA, <prefix>.header
+ * ("name\tstart\tlength"); mode "reads" only indexes an existing reads file. file2 is read in mode "fastq" only.
+ * AIX_ERR_ARG: unknown mode; AIX_ERR_IO: a file cannot be read / written. */
+int aix_compute_reads(const char* file1, const char* file2 /* nullable */, const char* mode, const char* prefix);
 /* The same normalisation for a buffer already in HBM (byte-identical output; the readers are finite-state transducers,
  * resolved with a parallel scan of per-chunk transition functions). format must be PLAIN, FASTA or FASTQ; d_out holds
  * len+1 bytes; *out_len is a HOST pointer; the call synchronises the stream. */

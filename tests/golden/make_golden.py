@@ -447,6 +447,55 @@ def make_compute_reads():
         print("compute_reads", name, [e for e in (".reads", ".ridx", ".header") if os.path.exists(os.path.join(w, name + e))])
 
 
+def make_compute_reads_edges():
+    """N4, malformed / awkward inputs (ours, tiny): truncated records with and without a final newline (std::getline leaves or erases
+    the string it failed to fill, and compute_reads.cpp goes on using it), a mate file that is shorter than its partner, lower case /
+    N / IUPAC letters in the mate that is reverse-complemented, FASTA with empty lines, empty records, text before the first header
+    and no final newline, a plain reads file with empty lines, and empty files. Inputs and the reference's outputs are committed."""
+    d = os.path.join(GOLD, "compute_reads")
+    w = os.path.join(TMP, "compute_reads_edges")
+    shutil.rmtree(w, ignore_errors=True)
+    os.makedirs(w)
+    rec = lambda name, seq, q="I": "@%s\n%s\n+\n%s\n" % (name, seq, q * len(seq))
+    files = {
+        "edge_se_trunc_nl.fastq": rec("a", "ACGTACGT") + rec("b", "TTGACA") + "@c\n",
+        "edge_se_trunc_nonl.fastq": rec("a", "ACGTACGT") + rec("b", "TTGACA") + "@header_only",
+        "edge_se_noplus.fastq": rec("a", "ACGTACGT") + "@b\nGGGTTT",
+        "edge_pe_R1.fastq": rec("p1", "ACGTACGTAA") + rec("p2", "CCCCGGGGTT") + rec("p3", "TTTTAAAACC"),
+        "edge_pe_R2_short_nonl.fastq": rec("p1", "acgtNNRYacgtTTGA", "F") + rec("p2", "GATTACAGATTACA", "#")[:-1],
+        "edge_pe_R2_iupac.fastq": rec("p1", "ACGTNRYKMSWBDHVacgtn-*") + rec("p2", "") + rec("p3", "A"),
+        "edge_multi.fasta": "stray line before any header\n>first one\nACGT\n\nAC GT\n>\n>empty record above\n>third\tx\nTTTT\n>last\nGG\nCC",
+        "edge_reads.txt": "ACGT\n\nAC~GT\nTTTT",
+        "edge_empty.txt": "",
+    }
+    for name, text in files.items():
+        open(os.path.join(d, name), "w").write(text)
+    cases = {
+        "edge_se_trunc_nl": ("edge_se_trunc_nl.fastq", "-", "se"),
+        "edge_se_trunc_nonl": ("edge_se_trunc_nonl.fastq", "-", "se"),
+        "edge_se_noplus": ("edge_se_noplus.fastq", "-", "se"),
+        "edge_pe_short": ("edge_pe_R1.fastq", "edge_pe_R2_short_nonl.fastq", "fastq"),
+        "edge_pe_iupac": ("edge_pe_R1.fastq", "edge_pe_R2_iupac.fastq", "fastq"),
+        "edge_pe_r1_short": ("edge_pe_R2_short_nonl.fastq", "edge_pe_R1.fastq", "fastq"),
+        "edge_fasta": ("edge_multi.fasta", "-", "fasta"),
+        "edge_reads": ("edge_reads.txt", "-", "reads"),
+        "edge_empty_se": ("edge_empty.txt", "-", "se"),
+        "edge_empty_pe": ("edge_empty.txt", "edge_pe_R1.fastq", "fastq"),
+        "edge_empty_fasta": ("edge_empty.txt", "-", "fasta"),
+        "edge_empty_reads": ("edge_empty.txt", "-", "reads"),
+    }
+    for name, (f1, f2, mode) in cases.items():
+        run([os.path.join(REF, "compute_reads"), os.path.join(d, f1), f2 if f2 == "-" else os.path.join(d, f2), mode, os.path.join(w, name)])
+        got = []
+        for ext in (".reads", ".ridx", ".header"):
+            src = os.path.join(w, name + ext)
+            if os.path.exists(src):
+                shutil.copy(src, os.path.join(d, name + ext))
+                got.append(ext)
+        print("compute_reads", name, got)
+    json.dump(cases, open(os.path.join(d, "edge_cases.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-13mer-pf", action="store_true", help="reuse data/all_13mers.pf if present")
@@ -466,6 +515,7 @@ if __name__ == "__main__":
         make_kmer_counter()
     if not only or "compute_reads" in only:
         make_compute_reads()
+        make_compute_reads_edges()
     if not only or "13" in only:
         pf = make_pf13(a.skip_13mer_pf)
         make_count13(pf)
