@@ -20,6 +20,7 @@ HEADER = os.path.join(ROOT, "include", "aindex_hip.h")
 AIX_OK = 0
 AIX_ERR_CONFLICT = -12
 AIX_ERR_ARG = -1
+AIX_ERR_FORMAT = -3
 FMT_AUTO, FMT_PLAIN, FMT_FASTA, FMT_FASTQ = -1, 0, 1, 2
 CANON_NONE, CANON_REF_X86, CANON_TRUE_RC = 0, 1, 2
 TOTAL_13MERS = 4 ** 13
@@ -100,6 +101,9 @@ SIGNATURES = {
     "aix_window_codes_dev": (i32, [vp, u64, i32, i32, vp, vp]),
     "aix_normalize_reads": (i32, [vp, u64, i32, i32, vp, C.POINTER(u64)]),
     "aix_compute_reads": (i32, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]),
+    "aix_dat_load": (i32, [C.c_char_p, i32, C.POINTER(u64), C.POINTER(vp), C.POINTER(vp)]),
+    "aix_pf_build_file": (i32, [C.c_char_p, C.POINTER(vp), C.POINTER(u64)]),
+    "aix_kmers_write_text": (i32, [C.c_char_p, vp, vp, u64, i32]),
     "aix_normalize_reads_dev": (i32, [vp, u64, i32, i32, vp, C.POINTER(u64), vp]),
     "aix_detect_format": (i32, [vp, u64]),
     "aix_synth_genome_dev": (i32, [u64, u64, vp, vp]),

@@ -1,4 +1,7 @@
-// aix_reads.hip — N4 row, host side: the step before counting (src/compute_reads.cpp:20-216). FASTQ (paired or single), FASTA or a
+// aix_reads.hip — host-side text formats on either side of the device path (no device work, no GPU needed): compute_reads below, and at
+// the end of the file the readers / writers of the tools' text files (.dat of compute_index, the keys file of compute_mphf_seq, the
+// k-mer list of kmer_counter), which the Python front ends used to walk line by line.
+// N4 row: the step before counting (src/compute_reads.cpp:20-216). FASTQ (paired or single), FASTA or a
 // plain reads file -> <prefix>.reads (one record per line; a pair as R1~revcomp(R2)), <prefix>.ridx ("rid\tstart\tend" per record) and,
 // for FASTA, <prefix>.header ("name\tstart\tlength"). Text reformatting bound by file I/O: no device work, no GPU needed; the inputs are
 // memory-mapped and walked once, the outputs leave through large buffers. Line rules are std::getline's: lines end at '\n', a final
@@ -9,8 +12,10 @@
 #include <unistd.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/aindex_hip.h"
 
@@ -166,4 +171,84 @@ extern "C" int aix_compute_reads(const char* file1, const char* file2, const cha
     }
     const bool ok_reads = plain || reads.close(), ok_ridx = ridx.close(), ok_header = !fasta || header.close();      // every file is closed
     return ok_reads && ok_ridx && ok_header ? AIX_OK : AIX_ERR_IO;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the tools' text files
+// ---------------------------------------------------------------------------------------------
+// .dat of compute_index ("kmer<ws>tf" per line; worker_for_fill_index, src/hash.cpp:681-702: `is >> kmer >> tf`, a missing or unreadable
+// count reads as 0, one beyond u32 as its maximum; mock: only the k-mer is read). Every k-mer must be 23 characters (AIX_ERR_FORMAT);
+// empty lines are skipped. *keys_out = n * 23 bytes, *tf_out = n counts (null when mock); both malloc'd (aix_free).
+extern "C" int aix_dat_load(const char* path, int mock, uint64_t* n_out, char** keys_out, uint32_t** tf_out) {
+    if (!path || !n_out || !keys_out || (!mock && !tf_out)) return AIX_ERR_ARG;
+    *n_out = 0; *keys_out = nullptr;
+    if (tf_out) *tf_out = nullptr;
+    Mapped a;
+    if (!a.open(path)) return AIX_ERR_IO;
+    auto is_ws = [](char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; };
+    uint64_t n = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        Lines L(a);
+        Line ln;
+        uint64_t i = 0;
+        while (L.getline(ln)) {
+            const char *p = ln.s, *e = ln.s + ln.len;
+            while (p < e && is_ws(*p)) ++p;
+            if (p == e) continue;                                         // empty line
+            const char* k0 = p;
+            while (p < e && !is_ws(*p)) ++p;
+            if (pass == 1) {
+                if (p - k0 != 23) { free(*keys_out); *keys_out = nullptr; if (tf_out) { free(*tf_out); *tf_out = nullptr; } return AIX_ERR_FORMAT; }
+                memcpy(*keys_out + 23 * i, k0, 23);
+                if (!mock) {
+                    while (p < e && is_ws(*p)) ++p;
+                    uint64_t v = 0;
+                    bool over = false;
+                    while (p < e && *p >= '0' && *p <= '9') { v = v * 10 + (uint64_t)(*p - '0'); if (v > 0xFFFFFFFFull) over = true, v = 0xFFFFFFFFull; ++p; }
+                    (*tf_out)[i] = over ? 0xFFFFFFFFu : (uint32_t)v;
+                }
+            }
+            ++i;
+        }
+        if (pass == 0) {
+            n = i;
+            *keys_out = (char*)malloc(n ? 23 * n : 1);
+            if (!*keys_out) return AIX_ERR_NOMEM;
+            if (!mock) { *tf_out = (uint32_t*)malloc(n ? 4 * n : 4); if (!*tf_out) { free(*keys_out); *keys_out = nullptr; return AIX_ERR_NOMEM; } }
+        }
+    }
+    *n_out = n;
+    return AIX_OK;
+}
+
+// compute_mphf_seq <keys.txt> (compute_mphf_generic.hpp:21-30): one key per line, any lengths -> the .pf image of aix_pf_build_ragged
+extern "C" int aix_pf_build_file(const char* keys_path, void** pf_out, uint64_t* pf_len) {
+    if (!keys_path || !pf_out || !pf_len) return AIX_ERR_ARG;
+    Mapped a;
+    if (!a.open(keys_path)) return AIX_ERR_IO;
+    std::string data;
+    std::vector<uint64_t> offs;
+    try {
+        data.reserve(a.n);
+        offs.push_back(0);
+        Lines L(a);
+        Line ln;
+        while (L.getline(ln)) { data.append(ln.s, ln.len); offs.push_back(data.size()); }
+    } catch (const std::bad_alloc&) { return AIX_ERR_NOMEM; }
+    return aix_pf_build_ragged(data.data(), offs.data(), offs.size() - 1, pf_out, pf_len);
+}
+
+// the k-mer list kmer_counter writes (count_kmers.cpp:362-382): "KMER\tcount\n" per entry, in the order given (the caller sorts);
+// keys are 2-bit codes of k bases, first base most significant
+extern "C" int aix_kmers_write_text(const char* path, const uint64_t* keys, const uint64_t* counts, uint64_t n, int k) {
+    if (!path || (n && (!keys || !counts)) || k < 1 || k > 32) return AIX_ERR_ARG;
+    Out o;
+    if (!o.open(path)) return AIX_ERR_IO;
+    char km[33];
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t c = keys[i];
+        for (int j = 0; j < k; ++j) km[j] = "ACGT"[(c >> (2 * (k - 1 - j))) & 3];
+        o.put(km, (size_t)k); o.put('\t'); o.num(counts[i]); o.put('\n');
+    }
+    return o.close() ? AIX_OK : AIX_ERR_IO;
 }

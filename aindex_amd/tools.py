@@ -50,12 +50,10 @@ def kmer_counter(argv) -> int:
         i += 1
     keys, counts = counting.count_distinct(open(argv[0], "rb").read(), k, canon, min_count, _lib.FMT_FASTA)
     order = np.argsort(-counts.astype(np.int64), kind="stable")       # count descending (ties: key ascending)
-    from .synth import decode_kmers
-    kmers = decode_kmers(keys[order], k)
-    lines = b"".join(bytes(a) + b"\t" + str(int(c)).encode() + b"\n" for a, c in zip(kmers, counts[order]))
-    for path in {argv[2], "output.txt"}:
-        with open(path, "wb") as f:
-            f.write(lines)
+    ks = np.ascontiguousarray(keys[order], dtype=np.uint64)
+    cs = np.ascontiguousarray(counts[order], dtype=np.uint64)
+    for path in {argv[2], "output.txt"}:                               # the text is written by the library (10^8 lines are no Python loop)
+        check(lib().aix_kmers_write_text(path.encode(), ks.ctypes.data_as(vp), cs.ctypes.data_as(vp), ks.shape[0], k), "aix_kmers_write_text")
     return 0
 
 
@@ -64,13 +62,14 @@ def compute_mphf_seq(argv) -> int:
     if len(argv) < 1:
         print("Expected: compute_mphf_seq <filename> [output_filename]", file=sys.stderr)
         return 1
-    keys = open(argv[0], "rb").read().split(b"\n")
-    if keys and keys[-1] == b"":
-        keys.pop()
-    pf = builder.build_pf(keys)
-    if len(argv) >= 2:
-        with open(argv[1], "wb") as f:
-            f.write(pf)
+    p, n = vp(), C.c_uint64()
+    check(lib().aix_pf_build_file(argv[0].encode(), C.byref(p), C.byref(n)), "aix_pf_build_file")
+    try:
+        if len(argv) >= 2:
+            with open(argv[1], "wb") as f:
+                f.write(C.string_at(p, n.value))
+    finally:
+        lib().aix_free(p)
     return 0
 
 
@@ -80,17 +79,21 @@ def compute_index(argv) -> int:
         print("Expected arguments: compute_index <dat_file> <pf_file> <output_prefix> <nthreads> <mock_flag>", file=sys.stderr)
         return 1
     mock = int(argv[4]) != 0
-    rows = [ln.split() for ln in open(argv[0], "rb").read().split(b"\n") if ln]
-    if any(len(r[0]) != 23 for r in rows):
+    nn, kp, tp = C.c_uint64(), vp(), vp()
+    st = lib().aix_dat_load(argv[0].encode(), int(mock), C.byref(nn), C.byref(kp), C.byref(tp))      # the .dat is parsed by the library
+    if st == _lib.AIX_ERR_FORMAT:
         print("compute_index: every key must be a 23-mer", file=sys.stderr)
         return 1
-    keys = np.frombuffer(b"".join(r[0] for r in rows), dtype=np.uint8)
-    tfs = None if mock else np.array([int(r[1]) for r in rows], dtype=np.uint32)
+    check(st, "aix_dat_load")
+    n = nn.value
     pf = np.frombuffer(open(argv[1], "rb").read(), dtype=np.uint8)
-    n = len(rows)
     checker, tf = np.empty(n, dtype=np.uint64), np.empty(n, dtype=np.uint32)
-    st = lib().aix_index_scatter(pf.ctypes.data_as(vp), pf.shape[0], keys.ctypes.data_as(vp), tfs.ctypes.data_as(vp) if tfs is not None else None,
-                                 n, 0, checker.ctypes.data_as(vp), tf.ctypes.data_as(vp))
+    try:
+        st = lib().aix_index_scatter(pf.ctypes.data_as(vp), pf.shape[0], kp, tp if not mock else None, n, 0, checker.ctypes.data_as(vp), tf.ctypes.data_as(vp))
+    finally:
+        lib().aix_free(kp)
+        if tp:
+            lib().aix_free(tp)
     if st == -12:
         print("Conflict!!", file=sys.stderr)
         return 12                                                       # reference: exit(12)

@@ -304,6 +304,15 @@ int aix_detect_format(const char* buf, uint64_t len);  /* count_kmers13.cpp:194-
  * ("name\tstart\tlength"); mode "reads" only indexes an existing reads file. file2 is read in mode "fastq" only.
  * AIX_ERR_ARG: unknown mode; AIX_ERR_IO: a file cannot be read / written. */
 int aix_compute_reads(const char* file1, const char* file2 /* nullable */, const char* mode, const char* prefix);
+/* The tools' text files, host side (native: the files hold 10^7..10^9 lines).
+ * aix_dat_load: the .dat of compute_index ("kmer<ws>tf" per line; worker_for_fill_index, src/hash.cpp:681-702: a missing or unreadable
+ *   count reads as 0, one beyond u32 as its maximum; mock != 0: k-mers only). Every k-mer must be 23 characters (AIX_ERR_FORMAT), empty
+ *   lines are skipped. *keys_out = n * 23 bytes, *tf_out = n counts (not written when mock); malloc'd, release with aix_free.
+ * aix_pf_build_file: compute_mphf_seq <keys.txt> (compute_mphf_generic.hpp:21-30): one key per line -> aix_pf_build_ragged.
+ * aix_kmers_write_text: the list kmer_counter writes (count_kmers.cpp:362-382), "KMER\tcount\n" per entry in the order given. */
+int aix_dat_load(const char* path, int mock, uint64_t* n_out, char** keys_out, uint32_t** tf_out /* nullable when mock */);
+int aix_pf_build_file(const char* keys_path, void** pf_out, uint64_t* pf_len);
+int aix_kmers_write_text(const char* path, const uint64_t* keys, const uint64_t* counts, uint64_t n, int k);
 /* The same normalisation for a buffer already in HBM (byte-identical output; the readers are finite-state transducers,
  * resolved with a parallel scan of per-chunk transition functions). format must be PLAIN, FASTA or FASTQ; d_out holds
  * len+1 bytes; *out_len is a HOST pointer; the call synchronises the stream. */

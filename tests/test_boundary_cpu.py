@@ -121,3 +121,48 @@ def test_host_normaliser_against_reference_written_reads_files(gold):
     for src, want, fmt in (("in_test.fasta", "fasta.reads", 1), ("../count13/synth.fa", "fasta_multi.reads", 1), ("in_test_se.fastq", "se.reads", 2)):
         raw = open(os.path.join(d, src), "rb").read()
         assert counting.normalize(raw, fmt, 0) == open(os.path.join(d, want), "rb").read(), src
+
+
+def test_native_text_formats_of_the_tools(tmp_path):
+    """Host routines behind the tools' text files (no GPU): the .dat parser of compute_index (`is >> kmer >> tf`, src/hash.cpp:681-702:
+    any blank separates, a missing / unreadable count is 0, one beyond u32 saturates, mock reads k-mers only, empty lines skipped, a
+    k-mer of another length is a format error), the k-mer list writer of kmer_counter (count_kmers.cpp:362-382) and the keys-file
+    front end of the MWHC builder (== the builder called on the same keys)."""
+    import ctypes as C
+    import numpy as np
+    from aindex_amd import _lib, builder
+    from aindex_amd._lib import lib, vp
+    L = lib()
+    k1, k2, k3, k4 = b"ACGTACGTACGTACGTACGTACG", b"TTTTTTTTTTTTTTTTTTTTTTT", b"GATTACAGATTACAGATTACAGA", b"CCCCCCCCCCCCCCCCCCCCCCC"
+    dat = tmp_path / "a.dat"
+    dat.write_bytes(k1 + b"\t7\n" + b"\n" + b"  " + k2 + b" \t 4294967295\n" + k3 + b"\n" + k4 + b"\t99999999999 trailing\n" + k1[::-1] + b"\tx12")
+    n, kp, tp = C.c_uint64(), vp(), vp()
+    assert L.aix_dat_load(str(dat).encode(), 0, C.byref(n), C.byref(kp), C.byref(tp)) == 0 and n.value == 5
+    keys = C.string_at(kp, 23 * 5)
+    tfs = np.frombuffer(C.string_at(tp, 4 * 5), dtype=np.uint32).tolist()
+    L.aix_free(kp); L.aix_free(tp)
+    assert keys == k1 + k2 + k3 + k4 + k1[::-1] and tfs == [7, 4294967295, 0, 4294967295, 0]
+    n2, kp2 = C.c_uint64(), vp()
+    assert L.aix_dat_load(str(dat).encode(), 1, C.byref(n2), C.byref(kp2), None) == 0 and n2.value == 5
+    assert C.string_at(kp2, 23 * 5) == keys
+    L.aix_free(kp2)
+    bad = tmp_path / "bad.dat"
+    bad.write_bytes(k1 + b"\t1\nACGT\t2\n")
+    assert L.aix_dat_load(str(bad).encode(), 0, C.byref(n), C.byref(kp), C.byref(tp)) == _lib.AIX_ERR_FORMAT
+    assert L.aix_dat_load(str(tmp_path / "missing.dat").encode(), 0, C.byref(n), C.byref(kp), C.byref(tp)) != 0
+    # writer: 2-bit codes, first base most significant
+    codes = np.array([0, 1, (1 << 46) - 1, 0b011011], dtype=np.uint64)
+    counts = np.array([5, 18446744073709551615, 1, 0], dtype=np.uint64)
+    out = tmp_path / "k.txt"
+    assert L.aix_kmers_write_text(str(out).encode(), codes.ctypes.data_as(vp), counts.ctypes.data_as(vp), 4, 23) == 0
+    assert out.read_bytes() == b"A" * 23 + b"\t5\n" + b"A" * 22 + b"C\t18446744073709551615\n" + b"T" * 23 + b"\t1\n" + b"A" * 20 + b"CGT\t0\n"
+    assert L.aix_kmers_write_text(str(out).encode(), codes.ctypes.data_as(vp), counts.ctypes.data_as(vp), 2, 3) == 0 and out.read_bytes() == b"AAA\t5\nAAC\t18446744073709551615\n"
+    # keys file -> .pf == the builder on the same keys (any lengths, no final newline)
+    keysf = tmp_path / "keys.txt"
+    ks = [b"ACGT", b"A", b"TTGACA", b"GATTACA", k1]
+    keysf.write_bytes(b"\n".join(ks))
+    p, ln = vp(), C.c_uint64()
+    assert L.aix_pf_build_file(str(keysf).encode(), C.byref(p), C.byref(ln)) == 0
+    img = C.string_at(p, ln.value)
+    L.aix_free(p)
+    assert img == builder.build_pf(ks)
