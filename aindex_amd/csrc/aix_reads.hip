@@ -252,3 +252,29 @@ extern "C" int aix_kmers_write_text(const char* path, const uint64_t* keys, cons
     }
     return o.close() ? AIX_OK : AIX_ERR_IO;
 }
+
+// the .ridx file compute_reads writes and load_reads_index reads back (python_wrapper.cpp:261-279): three unsigned decimals per line,
+// blank separated. *out = 3 * n values (rid, start, end per read), malloc'd (aix_free). A line with fewer than three numbers ends the
+// file like the reference's `while (fin >> rid >> start >> end)`.
+extern "C" int aix_ridx_load(const char* path, uint64_t* n_out, uint64_t** out) {
+    if (!path || !n_out || !out) return AIX_ERR_ARG;
+    *n_out = 0; *out = nullptr;
+    Mapped a;
+    if (!a.open(path)) return AIX_ERR_IO;
+    // `fin >> a >> b >> c` does not care about line structure: numbers separated by any white space, stop at the first thing that is no number
+    uint64_t cap = a.n / 6 + 3, m = 0;                                  // a number and its separator take at least two bytes
+    uint64_t* v = (uint64_t*)malloc(8 * cap);
+    if (!v) return AIX_ERR_NOMEM;
+    const char *p = a.p, *e = a.p + a.n;
+    while (p && p < e) {
+        while (p < e && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r' || *p == '\v' || *p == '\f')) ++p;
+        if (p == e || *p < '0' || *p > '9') break;
+        uint64_t x = 0;
+        while (p < e && *p >= '0' && *p <= '9') { x = x * 10 + (uint64_t)(*p - '0'); ++p; }
+        if (m == cap) { cap *= 2; uint64_t* w = (uint64_t*)realloc(v, 8 * cap); if (!w) { free(v); return AIX_ERR_NOMEM; } v = w; }
+        v[m++] = x;
+    }
+    *n_out = m / 3;                                                      // an incomplete last triple is not a read
+    *out = v;
+    return AIX_OK;
+}

@@ -111,7 +111,14 @@ class AindexWrapper:
     def load_reads_index(self, index_file: str):
         """:261-279 — `.ridx` lines "rid\tstart\tend"; intervals are (start, end + 1)."""
         self._need(index_file)
-        a = np.loadtxt(index_file, dtype=np.uint64, ndmin=2) if os.path.getsize(index_file) else np.zeros((0, 3), np.uint64)
+        import ctypes as C
+        from ._lib import lib, vp, check
+        n, p = C.c_uint64(), vp()
+        check(lib().aix_ridx_load(index_file.encode(), C.byref(n), C.byref(p)), "aix_ridx_load")      # parsed by the library (10^8 lines are no numpy.loadtxt job)
+        try:
+            a = np.frombuffer(C.string_at(p, 24 * n.value), dtype=np.uint64).reshape(-1, 3) if n.value else np.zeros((0, 3), np.uint64)
+        finally:
+            lib().aix_free(p)
         self._ridx_rid, self._ridx_start, self._ridx_end = a[:, 0].copy(), a[:, 1].copy(), a[:, 2].copy()
         self.n_reads = int(a.shape[0])
         # the reference scans its interval list linearly for every query (python_wrapper.cpp:66-74). When the intervals are

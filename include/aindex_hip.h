@@ -313,6 +313,9 @@ int aix_compute_reads(const char* file1, const char* file2 /* nullable */, const
 int aix_dat_load(const char* path, int mock, uint64_t* n_out, char** keys_out, uint32_t** tf_out /* nullable when mock */);
 int aix_pf_build_file(const char* keys_path, void** pf_out, uint64_t* pf_len);
 int aix_kmers_write_text(const char* path, const uint64_t* keys, const uint64_t* counts, uint64_t n, int k);
+/* The .ridx file ("rid\tstart\tend" per read) that compute_reads writes and AindexWrapper::load_reads_index reads back
+ * (python_wrapper.cpp:261-279: `fin >> rid >> start >> end` until it fails). *out = 3 * n values, malloc'd (aix_free). */
+int aix_ridx_load(const char* path, uint64_t* n_out, uint64_t** out);
 /* The same normalisation for a buffer already in HBM (byte-identical output; the readers are finite-state transducers,
  * resolved with a parallel scan of per-chunk transition functions). format must be PLAIN, FASTA or FASTQ; d_out holds
  * len+1 bytes; *out_len is a HOST pointer; the call synchronises the stream. */

@@ -166,3 +166,16 @@ def test_native_text_formats_of_the_tools(tmp_path):
     img = C.string_at(p, ln.value)
     L.aix_free(p)
     assert img == builder.build_pf(ks)
+    # .ridx: numbers separated by any white space, reading stops at the first thing that is no number, an incomplete triple is no read
+    r = tmp_path / "a.ridx"
+    r.write_bytes(b"0\t0\t150\n1\t151\t301\n 2 302\n452\n3\t453\n")
+    nn, pp = C.c_uint64(), vp()
+    assert L.aix_ridx_load(str(r).encode(), C.byref(nn), C.byref(pp)) == 0 and nn.value == 3
+    assert np.frombuffer(C.string_at(pp, 24 * 3), dtype=np.uint64).tolist() == [0, 0, 150, 1, 151, 301, 2, 302, 452]
+    L.aix_free(pp)
+    r.write_bytes(b"0\t0\t150\nx\t1\t2\n")
+    assert L.aix_ridx_load(str(r).encode(), C.byref(nn), C.byref(pp)) == 0 and nn.value == 1
+    L.aix_free(pp)
+    r.write_bytes(b"")
+    assert L.aix_ridx_load(str(r).encode(), C.byref(nn), C.byref(pp)) == 0 and nn.value == 0
+    L.aix_free(pp)
