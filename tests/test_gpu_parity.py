@@ -492,6 +492,10 @@ def test_positions_fill_msd_path_equals_sort_path_and_oracle(ix23, gold, small23
         finally:
             del os.environ["AIX_POSITIONS_PIECE"]
         assert np.array_equal(pos, want_pos)
+        # the shard protocol on top of it (fill counters of earlier shards handed in, file-relative offsets): three shards == the whole
+        from shard_helpers import positions_by_shards
+        sind, acc, _first = positions_by_shards(ix, buf, 3)
+        assert np.array_equal(sind, want_ind) and np.array_equal(acc, want_pos)
         # heavy slots: one read 700 times (its k-mers: 700 pairs each), tf raised to 1000 for half of them and to 150 for the rest
         prefix = canon_case["prefix"]
         checker = np.fromfile(prefix + ".kmers.bin", dtype=np.uint64)
