@@ -300,7 +300,8 @@ bool a2_msd_eligible(uint64_t nwin, uint64_t n) {
 // keys: the probe's output for the nwin windows of this piece (bucket, or >= n for none). filled: u32[n] occurrences of every
 // bucket in the pieces / shards before this one; advanced by this piece's tallies when `advance`.
 hipError_t a2_msd_place(const IndexDev& ix, const uint32_t* keys, uint64_t nwin, uint64_t piece_first, uint32_t* filled, bool advance, const uint64_t* d_indices,
-                        uint64_t* d_positions, hipStream_t s) {
+                        uint64_t* d_positions, hipStream_t s, bool* untouched) {
+    if (untouched) *untouched = false;
     const uint64_t n = ix.n;
     uint32_t Bh = 12;
     while (Bh < 32 && ((n - 1) >> Bh)) ++Bh;                   // slots are < 2^Bh
@@ -332,8 +333,8 @@ hipError_t a2_msd_place(const IndexDev& ix, const uint32_t* keys, uint64_t nwin,
                    o_ob = o_bbase + up256(4ull * (nbuckets + 1)), o_oo = o_ob + up256(4ull * nbuckets), o_rem = o_oo + up256(8ull * nbuckets),
                    o_parts = o_rem + up256(8ull * nwin), total = o_parts + 8ull * cap * K1_CH;
     uint8_t* w = nullptr;
-    hipError_t e = pool_alloc((void**)&w, total);
-    if (e != hipSuccess) return e;
+    hipError_t e = getenv("AIX_A2_TEST_NOMEM") ? hipErrorOutOfMemory : pool_alloc((void**)&w, total);      // test hook: the workspace "does not fit"
+    if (e != hipSuccess) { if (untouched) *untouched = true; return e; }     // the workspace did not fit: the caller may take the sort path, nothing was written
     A2Over* over = (A2Over*)w;
     uint16_t* dir_part = (uint16_t*)(w + o_dirp);
     uint16_t* dir_cnt = (uint16_t*)(w + o_dirc);

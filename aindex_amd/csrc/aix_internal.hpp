@@ -99,7 +99,7 @@ hipError_t positions_fill(const IndexDev& ix, const uint8_t* d_reads, uint64_t l
 // grouping of the probe's (bucket, offset) pairs without a full-width sort (aix_a2msd.hip): two-level MSD partition + per-bucket LDS stage
 bool a2_msd_eligible(uint64_t nwin, uint64_t n);
 hipError_t a2_msd_place(const IndexDev& ix, const uint32_t* keys, uint64_t nwin, uint64_t piece_first, uint32_t* filled, bool advance, const uint64_t* d_indices,
-                        uint64_t* d_positions, hipStream_t s);
+                        uint64_t* d_positions, hipStream_t s, bool* untouched = nullptr /* set when the call failed before writing anything (workspace allocation) */);
 hipError_t positions_bucket_counts(const IndexDev& ix, const uint8_t* d_reads, uint64_t len, uint64_t start, unsigned long long* d_counts, hipStream_t s);
 
 // distinct k-mers = sort + run-length of window codes; outputs hipMalloc'd (caller frees), d_codes is clobbered

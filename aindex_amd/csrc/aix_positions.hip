@@ -226,8 +226,11 @@ hipError_t positions_fill(const IndexDev& ix, const uint8_t* d_reads, uint64_t l
         e = hipGetLastError();
         if (e != hipSuccess) break;
         if (a2_msd_eligible(nwin, ix.n)) {                                      // grouping by MSD partition + per-bucket LDS stage (aix_a2msd.hip)
-            e = a2_msd_place(ix, keys, nwin, base_offset + w0, filled, more, d_indices, d_positions, s);
-            continue;
+            bool untouched = false;
+            e = a2_msd_place(ix, keys, nwin, base_offset + w0, filled, more, d_indices, d_positions, s, &untouched);
+            if (e == hipSuccess || !untouched) continue;
+            (void)hipGetLastError();                                            // its workspace (16 B per window + chunk slack) did not fit: nothing was written,
+            e = hipSuccess;                                                     // the sort path below needs about half of that
         }
         if (!skeys) {                                                           // short buffers: one stable radix sort of (bucket, offset)
             e = pool_alloc((void**)&skeys, 4 * pw);

@@ -492,6 +492,11 @@ def test_positions_fill_msd_path_equals_sort_path_and_oracle(ix23, gold, small23
         finally:
             del os.environ["AIX_POSITIONS_PIECE"]
         assert np.array_equal(pos, want_pos)
+        os.environ["AIX_A2_TEST_NOMEM"] = "1"                              # the MSD workspace "does not fit": the piece takes the sort path, same answer
+        try:
+            assert np.array_equal(ix.positions_fill(buf)[1], want_pos)
+        finally:
+            del os.environ["AIX_A2_TEST_NOMEM"]
         # the shard protocol on top of it (fill counters of earlier shards handed in, file-relative offsets): three shards == the whole
         from shard_helpers import positions_by_shards
         sind, acc, _first = positions_by_shards(ix, buf, 3)
