@@ -470,7 +470,10 @@ def count23_roofline(ix, windows, reads, kern_ms):
     per_window = 151.0 / 128.0 + p["bytes_per_hit_probe"] + 8.0
     achieved = windows * per_window / (kern_ms * 1e-3) / 1e9
     lines = p["lines_per_hit_probe"]
+    pmc = load_pmc_traffic("count23")                    # measured on a 10 M-read launch; `traffic` itself is only filled for that launch size
+    per_window_pmc = (pmc["bytes_per_launch"] / pmc["windows_per_launch"]) if (pmc and pmc.get("windows_per_launch")) else None
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "traffic_per_window_pmc": per_window_pmc,
             "kernel": "k_count23_fixed", "kernel_ms": kern_ms, "requested_bytes_per_window": per_window, "lines_per_window": lines,
             "windows_per_launch": windows, "reads_per_launch": reads, "probe": p["name"],
             "line_traffic_estimate": {"GBps": windows * (lines * 128.0 + 151.0 / 128.0 + 128.0) / (kern_ms * 1e-3) / 1e9,
