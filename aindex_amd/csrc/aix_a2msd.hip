@@ -6,11 +6,16 @@
 // the offsets themselves. So the pairs (h << 32 | offset) go through the two-level MSD partition of aix_msd.hpp on the bits of
 // h (unstable tile counting sorts, no order kept), which leaves buckets of ~10^3 pairs that span 2^rbits consecutive slots, and
 // one workgroup per bucket finishes inside LDS:
-//     counting sort by the slot remainder (one returning LDS atomic per pair), then every pair ranks itself among the offsets
-//     of its own slot (a slot holds tf[h] ~ coverage-many pairs), and writes its position.
+//     counting sort by the slot remainder (one returning LDS atomic per pair: its arrival number is its place in the slot's run; runs
+//     start at multiples of four entries and are padded with +infinity), then the lanes walk the GROUPED array, so that neighbouring
+//     lanes hold pairs of one slot and read its 16-byte record and its run at the same addresses (broadcasts): every pair ranks
+//     itself among the offsets of its slot (a slot holds tf[h] ~ coverage-many pairs) and writes its position. What a bucket needs
+//     from memory (bounds, first 1 024 pairs, indices / filled / tf of its slots) is fetched while the previous bucket is processed.
 // Slots, fill counters and output ranges of a bucket are contiguous, so the per-bucket global reads and the position writes
-// are dense. A bucket that does not fit (> A2_CAP pairs: a k-mer that occurs thousands of times in one piece) is set aside;
-// those buckets — and only those — are gathered and go through the radix sort + run placement the whole input used to take.
+// are dense. A slot with more than A2_HEAVY pairs is sorted in place by the whole workgroup. A bucket that does not fit (> A2_CAP
+// pairs: a k-mer that occurs thousands of times in one piece) is set aside; those buckets — and only those — are gathered and go
+// through the radix sort + run placement the whole input used to take. A piece whose workspace cannot be allocated takes that
+// path as a whole (positions_fill).
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
