@@ -101,6 +101,8 @@ struct aix_index {
     struct HostPipe* pipe = nullptr;           // pinned staging + streams of the large host-buffer batches (lazily built)
     std::mutex pipe_mutex;
     hipEvent_t work13_done = nullptr;          // recorded behind every counting call: the next one (any stream) waits for it before touching the workspace
+    hipStream_t probe_stream = nullptr;        // count23: the slot probe of piece i + 1 runs here while piece i is partitioned and added on the caller's stream
+    hipEvent_t probe_ev[2] = {nullptr, nullptr}, hist_ev[2] = {nullptr, nullptr}, start_ev = nullptr;
     uint64_t device_bytes = 0;
     bool perm13_bijective = false;             // 13-mer: code -> mphf slot is a bijection of [0, 4^13) (true for the all-13-mers .pf)
     bool canonical_only = false;
@@ -276,6 +278,9 @@ static void destroy(aix_index* h) {
     if (h->work13) (void)hipFree(h->work13);
     if (h->pipe) { free_host_pipe(h->pipe); h->pipe = nullptr; }
     if (h->work13_done) (void)hipEventDestroy(h->work13_done);
+    for (int i = 0; i < 2; ++i) { if (h->probe_ev[i]) (void)hipEventDestroy(h->probe_ev[i]); if (h->hist_ev[i]) (void)hipEventDestroy(h->hist_ev[i]); }
+    if (h->start_ev) (void)hipEventDestroy(h->start_ev);
+    if (h->probe_stream) (void)hipStreamDestroy(h->probe_stream);
     if (h->small_stream) (void)hipStreamDestroy(h->small_stream);
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_cov) (void)hipHostFree(h->pin_cov);
@@ -870,25 +875,51 @@ extern "C" int aix_count23_fixed_dev(aix_index_t* h, const char* d_plain, uint64
     if (const char* e = getenv("AIX_COUNT23_PIECE")) { const uint64_t v = strtoull(e, nullptr, 10); if (v >= 1 && v <= (1ull << 31)) piece = v; }
     const uint64_t pw = std::min(piece, nwin);
     const uint64_t part_bytes = (count13_workspace_bytes(pw + 12) + 255) / 256 * 256;
-    int st = ensure_count_workspace(h, part_bytes + 4 * pw, s);
-    if (st) return st;
-    uint32_t* slots = (uint32_t*)((uint8_t*)h->work13 + part_bytes);
-    HIPCHK(hipMemsetAsync(h->work13, 0, 4, s));                               // the error word of the partition workspace
     const IndexDev d = h->dev();
-    for (uint64_t first = 0; first < nwin; first += pw) {
+    // More than one piece: the probe of piece i + 1 (HBM lines + hash arithmetic, no LDS) runs on a second stream while piece i is
+    // partitioned and added on the caller's stream (LDS-bound, one 152 KiB workgroup per CU) — two slot buffers, one partition
+    // workspace, events both ways. AIX_COUNT23_OVERLAP=0 keeps everything on the caller's stream (A/B switch).
+    bool overlap = !d.mk && nwin > pw;
+    if (const char* e = getenv("AIX_COUNT23_OVERLAP")) overlap = overlap && atoi(e) != 0;
+    const uint64_t slot_bytes = (4 * pw + 255) / 256 * 256;
+    int st = ensure_count_workspace(h, part_bytes + (overlap ? 2 : 1) * slot_bytes, s);
+    if (st) return st;
+    uint32_t* slot_buf[2] = {(uint32_t*)((uint8_t*)h->work13 + part_bytes), (uint32_t*)((uint8_t*)h->work13 + part_bytes + (overlap ? slot_bytes : 0))};
+    HIPCHK(hipMemsetAsync(h->work13, 0, 4, s));                               // the error word of the partition workspace
+    if (overlap) {
+        if (!h->probe_stream) {
+            HIPCHK(hipStreamCreateWithFlags(&h->probe_stream, hipStreamNonBlocking));
+            for (int i = 0; i < 2; ++i) {
+                HIPCHK(hipEventCreateWithFlags(&h->probe_ev[i], hipEventDisableTiming));
+                HIPCHK(hipEventCreateWithFlags(&h->hist_ev[i], hipEventDisableTiming));
+            }
+            HIPCHK(hipEventCreateWithFlags(&h->start_ev, hipEventDisableTiming));
+        }
+        HIPCHK(hipEventRecord(h->start_ev, s));                                // the reads (and whatever else the caller queued) are ready when the first probe starts
+        HIPCHK(hipStreamWaitEvent(h->probe_stream, h->start_ev, 0));
+    }
+    IndexDev dc = d;
+    // the slot-stream probe of the counter runs best with two lanes per bucket line (38.7-40.4 against 42.5-42.7 ms per 10 M reads with
+    // eight, same box): nothing but the 4-byte slot leaves the kernel, so fewer, wider reads per probe win; lookups keep eight
+    if (!h->bk_lpp_set) dc.bk_lpp = 2;
+    uint64_t ip = 0;
+    for (uint64_t first = 0; first < nwin; first += pw, ++ip) {
         const uint64_t w = std::min(pw, nwin - first);
+        uint32_t* slots = slot_buf[overlap ? (ip & 1) : 0];
         if (d.mk) {                                                            // 32 consecutive windows per lane; word 1 of the workspace = "undecided windows" flag
             HIPCHK(hipMemsetAsync((uint32_t*)h->work13 + 1, 0, 4, s));
             HIPCHK(launch_stream23_slots(d, (const uint8_t*)d_plain + first, w + 22, canon_mode, slots, (uint32_t*)h->work13 + 1, s));
-        }
-        else {
-            // the slot-stream probe of the counter runs best with two lanes per bucket line (38.7-40.4 against 42.5-42.7 ms per 10 M reads with
-            // eight, same box): nothing but the 4-byte slot leaves the kernel, so fewer, wider reads per probe win; lookups keep eight
-            IndexDev dc = d;
-            if (!h->bk_lpp_set) dc.bk_lpp = 2;
+        } else if (overlap) {
+            const int b = (int)(ip & 1);
+            if (ip >= 2) HIPCHK(hipStreamWaitEvent(h->probe_stream, h->hist_ev[b], 0));      // piece ip - 2 has been read out of this buffer
+            HIPCHK(launch_probe23_slots(dc, (const uint8_t*)d_plain + first, w + 22, canon_mode, slots, h->probe_stream));
+            HIPCHK(hipEventRecord(h->probe_ev[b], h->probe_stream));
+            HIPCHK(hipStreamWaitEvent(s, h->probe_ev[b], 0));
+        } else {
             HIPCHK(launch_probe23_slots(dc, (const uint8_t*)d_plain + first, w + 22, canon_mode, slots, s));
         }
         HIPCHK(launch_histogram_slots(slots, w, h->work13, d_tf_out, h->n, s));
+        if (overlap) HIPCHK(hipEventRecord(h->hist_ev[ip & 1], s));
     }
     uint32_t dropped = 0;
     HIPCHK(hipMemcpyAsync(&dropped, h->work13, 4, hipMemcpyDeviceToHost, s));
