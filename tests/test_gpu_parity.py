@@ -1446,6 +1446,11 @@ def test_count23_histogram_backend_equals_atomics_and_oracle(canon_case, small23
                         ix.set_bucket_table(bk)
                         ix.set_minimizer_table(mk)
                         assert np.array_equal(ix.count23_fixed(buf, _lib.FMT_PLAIN, mode), want), (mode, piece, bk, mk)
+                    # (True, False) with several pieces runs the probe of the next piece on the handle's second stream; the same on one stream
+                    ix.set_bucket_table(True)
+                    monkeypatch.setenv("AIX_COUNT23_OVERLAP", "0")
+                    assert np.array_equal(ix.count23_fixed(buf, _lib.FMT_PLAIN, mode), want), (mode, piece, "one stream")
+                    monkeypatch.delenv("AIX_COUNT23_OVERLAP")
                 ix.set_bucket_table(True)
                 ix.set_minimizer_table(True)
                 monkeypatch.delenv("AIX_COUNT23_PIECE", raising=False)
