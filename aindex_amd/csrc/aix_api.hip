@@ -871,7 +871,10 @@ extern "C" int aix_count23_fixed_dev(aix_index_t* h, const char* d_plain, uint64
         hipEvent_t ev; hipStream_t st;
         ~RecordOnExit() { (void)hipEventRecord(ev, st); }
     } record_on_exit{h->work13_done, s};
-    uint64_t piece = 1ull << 28;                                               // windows per pass: 1 GiB of slots + ~1 GiB of partitions
+    // windows per pass. Every pass pays for its chunk directory (sort, clears) and leaves one partly filled 512-byte chunk per (workgroup,
+    // partition) pair — up to 2^20 of them — for the histogram kernel to read, so long passes win: 200 M reads in 809 / 788 / 775 / 772 ms with
+    // 2^28 / 2^29 / 2^30 / 2^31 windows per pass (same box). 2^30: 4 GiB of slots (twice with the second stream) + ~2.6 GiB of partitions.
+    uint64_t piece = 1ull << 30;
     if (const char* e = getenv("AIX_COUNT23_PIECE")) { const uint64_t v = strtoull(e, nullptr, 10); if (v >= 1 && v <= (1ull << 31)) piece = v; }
     const uint64_t pw = std::min(piece, nwin);
     const uint64_t part_bytes = (count13_workspace_bytes(pw + 12) + 255) / 256 * 256;
