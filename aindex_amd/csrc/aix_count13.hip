@@ -359,8 +359,9 @@ struct ChunkDesc {
 struct C13Shape { int tb, wpt; unsigned maxgrid; };
 static inline C13Shape c13_shape() {
     static const C13Shape sh = [] {
-        C13Shape v{1024, 32, 512};                                // one 152 KiB workgroup per CU: measured faster than two smaller ones (see the top of the file)
+        C13Shape v{1024, 32, 256};                                // one 152 KiB workgroup per CU, one per CU in the grid: measured faster than two smaller ones and than 512..1024 workgroups (4.23 / 4.28 / 4.32 / 4.33 ms at 256 / 512 / 768 / 1024)
         if (const char* e = getenv("AIX_C13_SHAPE")) { if (e[0] == 's') v = C13Shape{512, 24, 1024}; }
+        if (const char* e = getenv("AIX_C13_GRID")) { const int g = atoi(e); if (g >= 1 && g <= 4096) v.maxgrid = (unsigned)g; }      // A/B switch: workgroups of the split
         return v;
     }();
     return sh;

@@ -11,8 +11,9 @@ Q="--no-cpu-baseline --no-secondary --no-gather-probe"
 step "last: distinct23 / count13"
 timeout -k 10 600 python bench.py --workload distinct23 --reads 5000000 --steps 5 --warmup 1 > $O/bench_distinct23reads5000000.json 2> $O/b4.err || { tail -5 $O/b4.err; exit 5; }
 timeout -k 10 600 python bench.py --workload count13 --steps 5 --warmup 1 > $O/bench_count13.json 2> $O/b5.err || { tail -5 $O/b5.err; exit 5; }
+timeout -k 10 600 python bench.py --workload count23 --reads 10000000 --steps 10 --warmup 2 $Q > $O/bench_count23reads10000000.json 2> $O/b6.err || { tail -5 $O/b6.err; exit 5; }
 export TMPDIR=/tmp; cd /tmp
-for t in "dist23|--workload distinct23 --reads 5000000" "c13|--workload count13"; do tag=${t%%|*}; args=${t#*|}
+for t in "dist23|--workload distinct23 --reads 5000000" "c13|--workload count13" "c23|--workload count23 --reads 10000000"; do tag=${t%%|*}; args=${t#*|}
 rm -rf $O/stats/$tag
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats/$tag -- python3 $R/bench.py $args --steps 5 --warmup 1 $Q > $O/stats/$tag.json 2> $O/stats/$tag.err || exit 8
 done
