@@ -811,8 +811,13 @@ extern "C" int aix_count13_dev(aix_index_t* h, const char* d_plain, uint64_t len
         uint64_t piece = 1ull << 31;
         if (const char* e = getenv("AIX_COUNT13_PIECE")) { const uint64_t v = strtoull(e, nullptr, 10); if (v >= 1 && v <= (1ull << 31)) piece = v; }
         const uint64_t nwin = len >= 13 ? len - 12 : 0;
-        const uint64_t need = count13_workspace_bytes(std::min(nwin, piece) + 12);
-        { const int stw = ensure_count_workspace(h, need, s); if (stw) return stw; }
+        for (;;) {                                                               // a workspace that does not fit halves the piece (down to 4096 windows)
+            const uint64_t pw = std::min(nwin, piece);
+            const int stw = ensure_count_workspace(h, count13_workspace_bytes(pw + 12), s);
+            if (stw == AIX_OK) break;
+            if (stw != AIX_ERR_NOMEM || pw <= 4096) return stw;
+            piece = pw / 2;
+        }
         HIPCHK(hipMemsetAsync(d_tf_out, 0, 8 * AIX_TOTAL_13MERS, s));
         HIPCHK(hipMemsetAsync(h->work13, 0, 4, s));                               // the error word of the workspace
         for (uint64_t first = 0; first < nwin; first += piece) {
@@ -838,7 +843,16 @@ static int ensure_count_workspace(aix_index* h, uint64_t need, hipStream_t s) {
     if (need <= h->work13_bytes) return AIX_OK;
     HIPCHK(hipStreamSynchronize(s));
     if (h->work13) { (void)hipFree(h->work13); h->device_bytes -= h->work13_bytes; h->work13 = nullptr; h->work13_bytes = 0; }
-    HIPCHK(hipMalloc(&h->work13, need));
+    // AIX_COUNT_TEST_WORKSPACE_MAX: test hook, requests above this many bytes "do not fit"
+    const char* lim = getenv("AIX_COUNT_TEST_WORKSPACE_MAX");
+    const hipError_t e = (lim && need > strtoull(lim, nullptr, 10)) ? hipErrorOutOfMemory : hipMalloc(&h->work13, need);
+    if (e == hipErrorOutOfMemory) {
+        (void)hipGetLastError();                                               // the failed request is not a sticky error
+        h->work13 = nullptr;
+        set_last_error("count workspace of " + std::to_string(need) + " bytes does not fit in device memory");
+        return AIX_ERR_NOMEM;
+    }
+    HIPCHK(e);
     h->work13_bytes = need;
     h->device_bytes += need;
     return AIX_OK;
@@ -876,17 +890,24 @@ extern "C" int aix_count23_fixed_dev(aix_index_t* h, const char* d_plain, uint64
     // 2^28 / 2^29 / 2^30 / 2^31 windows per pass (same box). 2^30: 4 GiB of slots (twice with the second stream) + ~2.6 GiB of partitions.
     uint64_t piece = 1ull << 30;
     if (const char* e = getenv("AIX_COUNT23_PIECE")) { const uint64_t v = strtoull(e, nullptr, 10); if (v >= 1 && v <= (1ull << 31)) piece = v; }
-    const uint64_t pw = std::min(piece, nwin);
-    const uint64_t part_bytes = (count13_workspace_bytes(pw + 12) + 255) / 256 * 256;
     const IndexDev d = h->dev();
     // More than one piece: the probe of piece i + 1 (HBM lines + hash arithmetic, no LDS) runs on a second stream while piece i is
     // partitioned and added on the caller's stream (LDS-bound, one 152 KiB workgroup per CU) — two slot buffers, one partition
     // workspace, events both ways. AIX_COUNT23_OVERLAP=0 keeps everything on the caller's stream (A/B switch).
-    bool overlap = !d.mk && nwin > pw;
-    if (const char* e = getenv("AIX_COUNT23_OVERLAP")) overlap = overlap && atoi(e) != 0;
-    const uint64_t slot_bytes = (4 * pw + 255) / 256 * 256;
-    int st = ensure_count_workspace(h, part_bytes + (overlap ? 2 : 1) * slot_bytes, s);
-    if (st) return st;
+    // A workspace that does not fit (2^30 windows: ~10.6 GiB) halves the pass instead of failing the call (down to 4096 windows).
+    uint64_t pw, part_bytes, slot_bytes;
+    bool overlap;
+    for (;;) {
+        pw = std::min(piece, nwin);
+        part_bytes = (count13_workspace_bytes(pw + 12) + 255) / 256 * 256;
+        overlap = !d.mk && nwin > pw;
+        if (const char* e = getenv("AIX_COUNT23_OVERLAP")) overlap = overlap && atoi(e) != 0;
+        slot_bytes = (4 * pw + 255) / 256 * 256;
+        const int st = ensure_count_workspace(h, part_bytes + (overlap ? 2 : 1) * slot_bytes, s);
+        if (st == AIX_OK) break;
+        if (st != AIX_ERR_NOMEM || pw <= 4096) return st;
+        piece = pw / 2;
+    }
     uint32_t* slot_buf[2] = {(uint32_t*)((uint8_t*)h->work13 + part_bytes), (uint32_t*)((uint8_t*)h->work13 + part_bytes + (overlap ? slot_bytes : 0))};
     HIPCHK(hipMemsetAsync(h->work13, 0, 4, s));                               // the error word of the partition workspace
     if (overlap) {

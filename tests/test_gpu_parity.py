@@ -1264,6 +1264,48 @@ def test_count13_region_guard_and_foreign_pf(ix13, tmp_path, monkeypatch):
         assert fx.tf_ascii(q).tolist() == [int(want[m.lookup(q[i:i + 13])]) & 0xFFFFFFFF if m.lookup(q[i:i + 13]) < 4 ** 13 else 0 for i in range(0, len(q), 13)]
 
 
+def test_count_workspace_that_does_not_fit_halves_the_pass(small23_prefix, monkeypatch):
+    """The partition workspace of count13 / count23 is sized by the windows of one pass (2^30 windows: ~10.6 GiB). When it does not fit
+    (AIX_COUNT_TEST_WORKSPACE_MAX plays the full device) the pass is halved until it does, with the same counts; a limit nothing
+    fits under fails with AIX_ERR_NOMEM and leaves the handle usable."""
+    from pf13 import pf13_path
+    asc = synth.genome_ascii(15, 80_000)
+    reads = synth.reads_plain(16, asc, 4000, 150, n_rate_ppm=500).tobytes()
+    want13 = O.count13(O.OracleMphf(pf13_path()), reads, 0)
+    gold = open(small23_prefix + ".reads", "rb").read().replace(b"~", b"\n") * 10          # ~600 K windows: 19 tiles of the split kernel
+    want23 = O.OracleIndex23.from_prefix(small23_prefix).count23_fixed(gold, False, 1)
+    monkeypatch.setenv("AIX_COUNT23_HIST_MIN", "0")
+    for kind in ("13", "23"):
+        def run(limit):
+            if limit is None:
+                monkeypatch.delenv("AIX_COUNT_TEST_WORKSPACE_MAX", raising=False)
+            else:
+                monkeypatch.setenv("AIX_COUNT_TEST_WORKSPACE_MAX", str(limit))
+            ix = Index.open_13(pf13_path(), None) if kind == "13" else Index.open_23(small23_prefix + ".pf", small23_prefix + ".tf.bin", small23_prefix + ".kmers.bin")
+            try:
+                before = ix.info["device_bytes"]
+                got = ix.count13(reads, _lib.FMT_PLAIN) if kind == "13" else ix.count23_fixed(gold, _lib.FMT_PLAIN, 1)
+                return got, ix.info["device_bytes"] - before
+            finally:
+                ix.close()
+        want = want13 if kind == "13" else want23
+        got, full = run(None)
+        assert np.array_equal(got, want) and full > 0
+        got, half = run(full // 2)                                     # at least one halving
+        assert np.array_equal(got, want) and 0 < half <= full // 2
+        got, small = run(full // 5)
+        assert np.array_equal(got, want) and 0 < small <= full // 5
+        monkeypatch.setenv("AIX_COUNT_TEST_WORKSPACE_MAX", "1")
+        ix = Index.open_13(pf13_path(), None) if kind == "13" else Index.open_23(small23_prefix + ".pf", small23_prefix + ".tf.bin", small23_prefix + ".kmers.bin")
+        with pytest.raises(_lib.AixError) as ei:
+            ix.count13(reads, _lib.FMT_PLAIN) if kind == "13" else ix.count23_fixed(gold, _lib.FMT_PLAIN, 1)
+        assert ei.value.status == -4
+        monkeypatch.delenv("AIX_COUNT_TEST_WORKSPACE_MAX")
+        got = ix.count13(reads, _lib.FMT_PLAIN) if kind == "13" else ix.count23_fixed(gold, _lib.FMT_PLAIN, 1)
+        assert np.array_equal(got, want)
+        ix.close()
+
+
 def test_early_exit_walk_on_off(canon_case, ix23, q23):
     """Presence-mask early exit: identical answers in every combination of the three switches, on the canonical
     synthetic index and on the reference-built (non-canonical) golden index."""
