@@ -448,6 +448,7 @@ def apply_ab_switches(ix, a):
     if a.no_early_exit:
         ix.set_early_exit(False)
         _FLAGS[(id(ix), "early_exit")] = False
+    globals()["_BUCKET_LANES_GIVEN"] = bool(a.bucket_lanes) or bool(os.environ.get("AIX_BUCKET_LANES"))
     if a.no_bucket_table or a.bucket_lanes:
         ix.set_bucket_table(not a.no_bucket_table, a.bucket_lanes)
     if a.no_absence_filter:
@@ -459,6 +460,9 @@ def apply_ab_switches(ix, a):
 def info_flag(ix, name):
     """Host-side mirror of the A/B switches bench.py itself flipped (the library does not report them back)."""
     return _FLAGS.get((id(ix), name), True)
+
+
+_BUCKET_LANES_GIVEN = False          # set by main(): --bucket-lanes / AIX_BUCKET_LANES pin the lanes per bucket line for every consumer
 
 
 def count23_roofline(ix, windows, reads, kern_ms):
@@ -475,7 +479,8 @@ def count23_roofline(ix, windows, reads, kern_ms):
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
             "traffic_per_window_pmc": per_window_pmc,
             "kernel": "k_count23_fixed", "kernel_ms": kern_ms, "requested_bytes_per_window": per_window, "lines_per_window": lines,
-            "windows_per_launch": windows, "reads_per_launch": reads, "probe": p["name"],
+            "windows_per_launch": windows, "reads_per_launch": reads,
+            "probe": p["name"].replace("(8 lanes per line)", "(the counter's slot probe reads a line with 2 lanes unless --bucket-lanes says otherwise)") if not _BUCKET_LANES_GIVEN else p["name"],
             "line_traffic_estimate": {"GBps": windows * (lines * 128.0 + 151.0 / 128.0 + 128.0) / (kern_ms * 1e-3) / 1e9,
                                       "note": "128-byte lines the probes and the counter RMW move (estimate; `traffic` is the PMC figure)"},
             "reference_algorithm": {"bytes_per_window": 1.17 + 154.0 + 8.0,
