@@ -112,6 +112,12 @@ struct aix_index {
     bool early_exit = true;
     std::mutex count_mutex;
 
+    // the slot-stream consumers (count23's histogram path, the positions probe): two lanes per bucket line unless the caller chose a width
+    IndexDev dev_slots() const {
+        IndexDev d = dev();
+        if (!bk_lpp_set) d.bk_lpp = 2;
+        return d;
+    }
     IndexDev dev() const {
         IndexDev d{};
         d.m.recs = recs;
@@ -922,10 +928,9 @@ extern "C" int aix_count23_fixed_dev(aix_index_t* h, const char* d_plain, uint64
         HIPCHK(hipEventRecord(h->start_ev, s));                                // the reads (and whatever else the caller queued) are ready when the first probe starts
         HIPCHK(hipStreamWaitEvent(h->probe_stream, h->start_ev, 0));
     }
-    IndexDev dc = d;
     // the slot-stream probe of the counter runs best with two lanes per bucket line (38.7-40.4 against 42.5-42.7 ms per 10 M reads with
     // eight, same box): nothing but the 4-byte slot leaves the kernel, so fewer, wider reads per probe win; lookups keep eight
-    if (!h->bk_lpp_set) dc.bk_lpp = 2;
+    const IndexDev dc = h->dev_slots();
     uint64_t ip = 0;
     for (uint64_t first = 0; first < nwin; first += pw, ++ip) {
         const uint64_t w = std::min(pw, nwin - first);
@@ -1510,7 +1515,7 @@ extern "C" int aix_positions_fill(aix_index_t* h, const char* reads, uint64_t le
     HIPCHK(dpos.alloc(8 * total));
     if (len) HIPCHK(hipMemcpy(dreads.p, reads, len, hipMemcpyHostToDevice));
     HIPCHK(hipMemset(dpos.p, 0, 8 * total));
-    HIPCHK(positions_fill(h->dev(), (const uint8_t*)dreads.p, len, a2_start(reads, len, h->k), (const uint64_t*)dind.p, (uint64_t*)dpos.p, piece, nullptr, 0, 0));
+    HIPCHK(positions_fill(h->dev_slots(), (const uint8_t*)dreads.p, len, a2_start(reads, len, h->k), (const uint64_t*)dind.p, (uint64_t*)dpos.p, piece, nullptr, 0, 0));
     HIPCHK(hipMemcpy(positions_out, dpos.p, 8 * total, hipMemcpyDeviceToHost));
     return AIX_OK;
 }
@@ -1546,7 +1551,7 @@ extern "C" int aix_positions_fill_dev(aix_index_t* h, const char* d_reads, uint6
     if (total == 0) return AIX_OK;
     if (!d_positions_out || positions_cap < total) return AIX_ERR_ARG;
     HIPCHK(hipMemsetAsync(d_positions_out, 0, 8 * total, s));
-    HIPCHK(positions_fill(h->dev(), (const uint8_t*)d_reads, len, start, d_indices_out, d_positions_out, piece, nullptr, 0, s));
+    HIPCHK(positions_fill(h->dev_slots(), (const uint8_t*)d_reads, len, start, d_indices_out, d_positions_out, piece, nullptr, 0, s));
     return AIX_OK;
 }
 
@@ -1572,7 +1577,7 @@ extern "C" int aix_positions_bucket_counts(aix_index_t* h, const char* reads, ui
     HIPCHK(dcnt.alloc(8 * n));
     if (len) HIPCHK(hipMemcpy(dreads.p, reads, len, hipMemcpyHostToDevice));
     HIPCHK(hipMemset(dcnt.p, 0, 8 * n));
-    HIPCHK(positions_bucket_counts(h->dev(), (const uint8_t*)dreads.p, len, first_shard ? a2_start(reads, len, h->k) : 0, (unsigned long long*)dcnt.p, 0));
+    HIPCHK(positions_bucket_counts(h->dev_slots(), (const uint8_t*)dreads.p, len, first_shard ? a2_start(reads, len, h->k) : 0, (unsigned long long*)dcnt.p, 0));
     HIPCHK(hipMemcpy(counts_out, dcnt.p, 8 * n, hipMemcpyDeviceToHost));
     return AIX_OK;
 }
@@ -1600,7 +1605,7 @@ extern "C" int aix_positions_fill_shard(aix_index_t* h, const char* reads, uint6
     }
     if (len) HIPCHK(hipMemcpy(dreads.p, reads, len, hipMemcpyHostToDevice));
     HIPCHK(hipMemset(dpos.p, 0, 8 * total));
-    HIPCHK(positions_fill(h->dev(), (const uint8_t*)dreads.p, len, first_shard ? a2_start(reads, len, h->k) : 0, (const uint64_t*)dind.p, (uint64_t*)dpos.p, piece,
+    HIPCHK(positions_fill(h->dev_slots(), (const uint8_t*)dreads.p, len, first_shard ? a2_start(reads, len, h->k) : 0, (const uint64_t*)dind.p, (uint64_t*)dpos.p, piece,
                           filled_init ? (const uint32_t*)dfill.p : nullptr, base_offset, 0));
     HIPCHK(hipMemcpy(positions_out, dpos.p, 8 * total, hipMemcpyDeviceToHost));
     return AIX_OK;
@@ -1639,7 +1644,7 @@ extern "C" int aix_positions_bucket_counts_dev(aix_index_t* h, const char* d_rea
     DevGuard g(h->device);
     if (h->n == 0) return AIX_OK;
     HIPCHK(hipMemsetAsync(d_counts_out, 0, 8 * h->n, (hipStream_t)stream));
-    HIPCHK(positions_bucket_counts(h->dev(), (const uint8_t*)d_reads, len, start, (unsigned long long*)d_counts_out, (hipStream_t)stream));
+    HIPCHK(positions_bucket_counts(h->dev_slots(), (const uint8_t*)d_reads, len, start, (unsigned long long*)d_counts_out, (hipStream_t)stream));
     return AIX_OK;
 }
 
@@ -1650,7 +1655,7 @@ extern "C" int aix_positions_fill_shard_dev(aix_index_t* h, const char* d_reads,
     if (h->n == 0) return AIX_OK;
     uint64_t piece = 0;
     if (const char* e = getenv("AIX_POSITIONS_PIECE")) piece = strtoull(e, nullptr, 10);
-    HIPCHK(positions_fill(h->dev(), (const uint8_t*)d_reads, len, start, d_indices, d_positions, piece, d_filled_init, base_offset, (hipStream_t)stream));
+    HIPCHK(positions_fill(h->dev_slots(), (const uint8_t*)d_reads, len, start, d_indices, d_positions, piece, d_filled_init, base_offset, (hipStream_t)stream));
     return AIX_OK;
 }
 

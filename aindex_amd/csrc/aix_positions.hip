@@ -37,6 +37,7 @@ __global__ void __launch_bounds__(kB) k_tf_u64(const KeyRec* __restrict__ recs, 
 // bucket of every window (key = n for "no bucket"): hash.cpp:1004-1052. Wave-uniform loop: the verification-table probe is
 // wave-cooperative (aix_device.hpp: bucket_probe_wave); a forward-strand window with bytes outside ACGT hashes its RAW bytes
 // (:1032-1040), which the table cannot answer, and goes through the MPHF.
+template <int LPP>
 __global__ void __launch_bounds__(kB) k_a2_probe(const IndexDev ix, const uint8_t* __restrict__ buf, uint64_t nwin, uint64_t start, uint32_t* __restrict__ keys) {
     const uint64_t stride = (uint64_t)gridDim.x * kB;
     const uint64_t FULL = ~0ULL, LAST7 = 0x00FFFFFFFFFFFFFFULL;
@@ -66,7 +67,7 @@ __global__ void __launch_bounds__(kB) k_a2_probe(const IndexDev ix, const uint8_
         bool mphf = rest;
         if (ix.bk) {
             const bool use = rest && tab;
-            const BkRes k = bucket_probe_wave<8>(ix.bk, ix.nb, use, a, want);
+            const BkRes k = bucket_probe_wave<LPP>(ix.bk, ix.nb, use, a, want);
             if (use) {
                 if (k.found) key = k.slot;
                 mphf = !k.found && k.overflow;
@@ -146,7 +147,16 @@ __global__ void __launch_bounds__(kB) k_a2_tally(const uint32_t* __restrict__ ke
 
 static void launch_a2_probe(const IndexDev& ix, const uint8_t* d_reads, uint64_t nwin, uint64_t start, uint32_t* keys, hipStream_t s) {
     if (ix.k == 13) hipLaunchKernelGGL(k_a2_probe13, dim3(grid_of(nwin)), dim3(kB), 0, s, ix.perm13, d_reads, nwin, start, keys);
-    else hipLaunchKernelGGL(k_a2_probe, dim3(grid_of(nwin)), dim3(kB), 0, s, ix, d_reads, nwin, start, keys);
+    else {
+        // lanes that share one bucket line (IndexDev::bk_lpp; the ABI hands in 2 unless the caller chose a width: like count23's slot probe,
+        // nothing but a 4-byte slot leaves this kernel, and two lanes per line measured 28.5-29.9 against 29.6-30.7 ms per 5 M reads with eight,
+        // three alternating repetitions on one box). AIX_A2_PROBE_LANES: A/B switch
+        static const int forced = [] { const char* e = getenv("AIX_A2_PROBE_LANES"); const int v = e ? atoi(e) : 0; return v == 2 || v == 4 || v == 8 ? v : 0; }();
+        const int lanes = forced ? forced : (int)ix.bk_lpp;
+        if (lanes == 2) hipLaunchKernelGGL(k_a2_probe<2>, dim3(grid_of(nwin)), dim3(kB), 0, s, ix, d_reads, nwin, start, keys);
+        else if (lanes == 4) hipLaunchKernelGGL(k_a2_probe<4>, dim3(grid_of(nwin)), dim3(kB), 0, s, ix, d_reads, nwin, start, keys);
+        else hipLaunchKernelGGL(k_a2_probe<8>, dim3(grid_of(nwin)), dim3(kB), 0, s, ix, d_reads, nwin, start, keys);
+    }
 }
 
 hipError_t exclusive_scan_u32(const uint32_t* d_in, uint32_t* d_out, uint64_t n, hipStream_t s) {
