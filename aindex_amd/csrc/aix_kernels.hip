@@ -10,8 +10,12 @@ namespace aix {
 
 static constexpr int kBlock = 256;
 static inline unsigned grid_for(uint64_t work, unsigned per_block = kBlock) {
-    uint64_t b = (work + per_block - 1) / per_block;
-    const uint64_t cap = 256ull * 32ull;          // 256 CUs x 32 resident-ish blocks, grid-stride beyond
+    // Grid-stride kernels. Up to 8192 workgroups one trip each; beyond that a quarter of the trips' worth of workgroups — a wave keeps at
+    // least four trips, which is what the lookups' FilterGauge needs to adapt — up to 256 per CU: finer workgroups balance the tail better
+    // than 32 per CU did (100 M lookups 2.116 against 2.16 ms, coverage 29.9 against 31.4 ms, count23 38.3 against 38.7 ms, one box).
+    static const uint64_t per_cu = [] { const char* e = getenv("AIX_GRID_PER_CU"); const long v = e ? atol(e) : 0; return (uint64_t)(v >= 1 && v <= 1024 ? v : 256); }();   // A/B switch
+    const uint64_t need = (work + per_block - 1) / per_block, cap = 256ull * per_cu;
+    uint64_t b = std::max(std::min<uint64_t>(need, 8192), need / 4);
     if (b > cap) b = cap;
     if (b == 0) b = 1;
     return (unsigned)b;

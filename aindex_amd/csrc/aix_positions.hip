@@ -18,7 +18,7 @@ namespace aix {
 static constexpr int kB = 256;
 static inline unsigned grid_of(uint64_t work) {
     uint64_t b = (work + kB - 1) / kB;
-    if (b > 8192) b = 8192;
+    if (b > 8192) b = std::max<uint64_t>(8192, std::min<uint64_t>(b / 4, 65536));     // as grid_for of aix_kernels.hip: finer workgroups for long buffers
     if (b == 0) b = 1;
     return (unsigned)b;
 }
