@@ -41,6 +41,15 @@ class Info(C.Structure):
                 ("minimizer_lines", C.c_uint64), ("minimizer_unfiled_keys", C.c_uint64)]
 
 
+class IngestStats(C.Structure):
+    _fields_ = [("bytes_in", C.c_uint64), ("plain_bytes", C.c_uint64), ("parts", C.c_uint64), ("part_bytes", C.c_uint64), ("pieces", C.c_uint64),
+                ("pinned_bytes", C.c_uint64), ("device_bytes", C.c_uint64), ("workspace_bytes", C.c_uint64), ("seconds_total", C.c_double), ("seconds_read", C.c_double),
+                ("seconds_wait", C.c_double), ("seconds_compute", C.c_double), ("seconds_output", C.c_double)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
 _LIB = None
 vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
 
@@ -86,6 +95,10 @@ SIGNATURES = {
     "aix_count13_dev": (i32, [vp, vp, u64, vp, vp]),
     "aix_count23_fixed": (i32, [vp, vp, u64, i32, i32, vp]),
     "aix_count23_fixed_dev": (i32, [vp, vp, u64, i32, vp, vp]),
+    "aix_count13_file": (i32, [vp, C.c_char_p, i32, C.c_char_p, vp, C.POINTER(IngestStats)]),
+    "aix_count23_fixed_file": (i32, [vp, C.c_char_p, i32, i32, vp, C.POINTER(IngestStats)]),
+    "aix_count_distinct_file": (i32, [C.c_char_p, i32, i32, i32, u64, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), C.POINTER(IngestStats)]),
+    "aix_merge_runs_dev": (i32, [vp, vp, vp, u32, u64, i32, vp, C.POINTER(vp)]),
     "aix_count_distinct": (i32, [vp, u64, i32, i32, i32, u64, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]),
     "aix_positions_fill": (i32, [vp, vp, u64, vp, vp, u64, C.POINTER(u64)]),
     "aix_positions_total": (i32, [vp, C.POINTER(u64)]),
@@ -151,10 +164,11 @@ def build(force: bool = False) -> str:
 def lib():
     global _LIB
     if _LIB is None:
-        try:
-            import torch  # noqa: F401  (loads PyTorch's HIP runtime first; see module docstring)
-        except Exception:
-            pass
+        if not os.environ.get("AIX_NO_TORCH"):                  # the command-line tools set it: they never touch a tensor, and importing torch costs seconds
+            try:
+                import torch  # noqa: F401  (loads PyTorch's HIP runtime first; see module docstring)
+            except Exception:
+                pass
         if not os.path.exists(LIB_PATH):
             build()
         L = C.CDLL(LIB_PATH)

@@ -94,14 +94,7 @@ def merge_counts_t(keys_t, counts_t, min_count: int = 1):
     return keys, counts
 
 
-def count_distinct(buf: bytes, k: int, canon_mode: int = _lib.CANON_TRUE_RC, min_count: int = 1, fmt: int = _lib.FMT_FASTA,
-                   device: int = 0):
-    """kmer_counter replacement for a host buffer, entirely behind the C ABI (aix_count_distinct: HIP window kernel +
-    rocPRIM sort / run-length). Returns (keys uint64, counts uint64) sorted by key."""
-    a = np.frombuffer(buf, dtype=np.uint8)
-    kp, cp, n = vp(), vp(), C.c_uint64()
-    check(lib().aix_count_distinct(a.ctypes.data_as(vp), a.shape[0], fmt, k, canon_mode, min_count, device, C.byref(kp), C.byref(cp), C.byref(n)),
-          "aix_count_distinct")
+def _take_distinct(kp, cp, n):
     try:
         m = n.value
         if m == 0 or not kp.value or not cp.value:
@@ -112,3 +105,49 @@ def count_distinct(buf: bytes, k: int, canon_mode: int = _lib.CANON_TRUE_RC, min
         lib().aix_free(kp)
         lib().aix_free(cp)
     return keys, counts
+
+
+def count_distinct_file(path: str, k: int, canon_mode: int = _lib.CANON_TRUE_RC, min_count: int = 1, fmt: int = _lib.FMT_FASTA, device: int = 0):
+    """kmer_counter on a FILE, streamed (aix_count_distinct_file): parts of the file cross the link while earlier ones are normalised and
+    appended to the current piece; pieces are counted as they fill and their sorted sets merged. Returns (keys, counts, stats dict)."""
+    import os
+    kp, cp, n = vp(), vp(), C.c_uint64()
+    st = _lib.IngestStats()
+    check(lib().aix_count_distinct_file(os.fsencode(path), fmt, k, canon_mode, min_count, device, C.byref(kp), C.byref(cp), C.byref(n), C.byref(st)),
+          f"aix_count_distinct_file({path})")
+    keys, counts = _take_distinct(kp, cp, n)
+    return keys, counts, st.as_dict()
+
+
+def merge_runs_t(keys_t, counts_t, run_offsets, min_count: int = 1):
+    """Device tensors holding sorted, repeat-free runs back to back (run r = [run_offsets[r], run_offsets[r + 1])) -> (keys ascending,
+    summed counts >= min_count), int64 tensors (u64 bit patterns). aix_merge_runs_dev: a tree of two-way merges, no sort."""
+    import torch
+    dev = keys_t.device
+    keys_t, counts_t = keys_t.contiguous(), counts_t.contiguous()
+    offs = np.ascontiguousarray(run_offsets, dtype=np.uint64)
+    res, n = vp(), C.c_uint64()
+    with torch.cuda.device(dev):
+        stream = vp(torch.cuda.current_stream().cuda_stream)
+        check(lib().aix_merge_runs_dev(vp(keys_t.data_ptr()) if keys_t.numel() else None, vp(counts_t.data_ptr()) if keys_t.numel() else None,
+                                       offs.ctypes.data_as(vp), offs.shape[0] - 1, min_count, dev.index, stream, C.byref(res)), "aix_merge_runs_dev")
+        try:
+            check(lib().aix_distinct_size(res, C.byref(n)), "aix_distinct_size")
+            keys = torch.empty(n.value, dtype=torch.int64, device=dev)
+            counts = torch.empty(n.value, dtype=torch.int64, device=dev)
+            check(lib().aix_distinct_copy_dev(res, vp(keys.data_ptr()) if n.value else None, vp(counts.data_ptr()) if n.value else None, stream),
+                  "aix_distinct_copy_dev")
+        finally:
+            lib().aix_distinct_free(res)
+    return keys, counts
+
+
+def count_distinct(buf: bytes, k: int, canon_mode: int = _lib.CANON_TRUE_RC, min_count: int = 1, fmt: int = _lib.FMT_FASTA,
+                   device: int = 0):
+    """kmer_counter replacement for a host buffer, entirely behind the C ABI (aix_count_distinct: HIP window kernel +
+    rocPRIM sort / run-length). Returns (keys uint64, counts uint64) sorted by key."""
+    a = np.frombuffer(buf, dtype=np.uint8)
+    kp, cp, n = vp(), vp(), C.c_uint64()
+    check(lib().aix_count_distinct(a.ctypes.data_as(vp), a.shape[0], fmt, k, canon_mode, min_count, device, C.byref(kp), C.byref(cp), C.byref(n)),
+          "aix_count_distinct")
+    return _take_distinct(kp, cp, n)

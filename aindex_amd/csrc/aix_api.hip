@@ -20,133 +20,12 @@
 #include "../../include/aindex_hip.h"
 #include "aix_internal.hpp"
 
-using namespace aix;
-
-#define HIPCHK(expr)                                                                          \
-    do {                                                                                      \
-        hipError_t _e = (expr);                                                               \
-        if (_e != hipSuccess) {                                                               \
-            set_last_error(std::string(#expr) + ": " + hipGetErrorString(_e));                \
-            return AIX_ERR_HIP;                                                               \
-        }                                                                                     \
-    } while (0)
+#include "aix_handle.hpp"
+#include "aix_ingest.hpp"
 
 static thread_local std::string g_last_error;
-static void set_last_error(const std::string& s) { g_last_error = s; }
+void set_last_error(const std::string& s) { g_last_error = s; }
 
-struct DevGuard {   // switch to the handle's device for the duration of a call, then restore
-    int prev = -1;
-    bool ok = false;
-    explicit DevGuard(int dev) {
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        ok = (hipSetDevice(dev) == hipSuccess);
-    }
-    ~DevGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
-};
-
-struct DevBuf {                     // per-call temporary from the scratch pool, used on ONE stream (default: the null stream)
-    void* p = nullptr;
-    hipStream_t st = nullptr;
-    DevBuf() = default;
-    explicit DevBuf(hipStream_t s) : st(s) {}
-    DevBuf(const DevBuf&) = delete;
-    DevBuf& operator=(const DevBuf&) = delete;
-    bool pooled = true;
-    hipError_t alloc(uint64_t bytes) { return pool_alloc(&p, bytes ? bytes : 1); }
-    // one-shot staging (index load): straight from the driver and straight back, never parked in the scratch cache
-    hipError_t alloc_once(uint64_t bytes) { pooled = false; return hipMalloc(&p, bytes ? bytes : 1); }
-    // a block goes back to the pool idle: wait for the stream it was used on (not for the whole device — other handles and
-    // other host threads keep running; error paths leave through here too)
-    ~DevBuf() { if (p) { (void)hipStreamSynchronize(st); if (pooled) pool_free(p); else (void)hipFree(p); } }
-};
-
-struct aix_index {
-    int device = 0;
-    uint32_t k = 0;
-    uint64_t n = 0;
-    // .pf header
-    uint64_t mphf_n = 0, D = 0, seed = 0, B = 0, W = 0;
-    // HBM
-    BvRec* recs = nullptr;
-    EeRec* ee = nullptr;                       // early-exit table (23-mer handles with keys)
-    KeyRec* keys = nullptr;
-    BkEntry* bk = nullptr;                     // verification table: nb buckets of eight {code, tf, slot} entries (one 128-byte line each)
-    uint32_t nb = 0;
-    uint32_t bk_lpp = 8;                       // lanes that share one bucket read
-    bool bk_lpp_set = false;                   // chosen by the caller (AIX_BUCKET_LANES / aix_index_set_bucket_table): then every consumer uses it
-    uint64_t bk_unfiled = 0;                   // keys beyond the eighth of their bucket (answered through the MPHF)
-    bool bk_enabled = true;
-    BkEntry* mk = nullptr;                     // minimizer-keyed copy of the table for the streaming counter: entries grouped by minimizer bucket
-    uint32_t* mk_off = nullptr;                // nbm + 1 offsets into mk
-    uint32_t mk_cap = 16;                      // entries of a bucket a lane of the streaming counter reads
-    uint32_t nbm = 0;
-    uint64_t mk_unfiled = 0;
-    bool mk_enabled = true;
-    uint64_t* bloom = nullptr;                 // absence filter in front of the table (lookups / coverage)
-    uint32_t nbloom = 0;
-    bool bloom_enabled = true;
-    uint64_t* tf13_mphf = nullptr;
-    uint64_t* tf13_code = nullptr;
-    uint32_t* perm13 = nullptr;
-    unsigned long long* scratch13 = nullptr;   // code-ordered count table, lazily allocated
-    void* work13 = nullptr;                    // partition workspace of the atomic-free counter (grow-only)
-    uint64_t work13_bytes = 0;
-    // tiny host batches (a Python loop over index[kmer]): pinned, device-mapped staging so that a call is one memcpy into
-    // host memory, one launch and one synchronise — no hipMemcpy round trips
-    void* pin_in = nullptr;
-    void* pin_out[3] = {nullptr, nullptr, nullptr};
-    std::mutex small_mutex;
-    hipStream_t small_stream = nullptr;
-    void* pin_cov = nullptr;                   // pinned, device-mapped staging of small coverage requests (kCovPin bytes)
-    struct HostPipe* pipe = nullptr;           // pinned staging + streams of the large host-buffer batches (lazily built)
-    std::mutex pipe_mutex;
-    hipEvent_t work13_done = nullptr;          // recorded behind every counting call: the next one (any stream) waits for it before touching the workspace
-    hipStream_t probe_stream = nullptr;        // count23: the slot probe of piece i + 1 runs here while piece i is partitioned and added on the caller's stream
-    hipEvent_t probe_ev[2] = {nullptr, nullptr}, hist_ev[2] = {nullptr, nullptr}, start_ev = nullptr;
-    uint64_t device_bytes = 0;
-    bool perm13_bijective = false;             // 13-mer: code -> mphf slot is a bijection of [0, 4^13) (true for the all-13-mers .pf)
-    bool canonical_only = false;
-    bool canonical_fastpath = true;
-    bool has_fp = false;
-    bool fp_filter = true;
-    bool early_exit = true;
-    std::mutex count_mutex;
-
-    // the slot-stream consumers (count23's histogram path, the positions probe): two lanes per bucket line unless the caller chose a width
-    IndexDev dev_slots() const {
-        IndexDev d = dev();
-        if (!bk_lpp_set) d.bk_lpp = 2;
-        return d;
-    }
-    IndexDev dev() const {
-        IndexDev d{};
-        d.m.recs = recs;
-        d.m.ee = ee;
-        d.m.D = D;
-        d.m.seed = seed;
-        d.m.nrecs = (B + 15) / 16;
-        d.m.fm = make_fastmod(D);
-        d.keys = keys;
-        d.n = n;
-        d.tf13_code = tf13_code;
-        d.tf13_mphf = tf13_mphf;
-        d.perm13 = perm13;
-        d.canonical_only = (canonical_only && canonical_fastpath) ? 1u : 0u;
-        d.k = k;
-        d.use_fp = (has_fp && fp_filter) ? 1u : 0u;
-        d.early_exit = (has_fp && ee && early_exit) ? 1u : 0u;
-        d.bk = (bk && bk_enabled) ? bk : nullptr;
-        d.nb = nb;
-        d.bk_lpp = bk_lpp;
-        d.bloom = (d.bk && bloom && bloom_enabled) ? bloom : nullptr;
-        d.nbloom = nbloom;
-        d.mk = (d.bk && mk && mk_enabled) ? mk : nullptr;
-        d.nbm = nbm;
-        d.mk_off = mk_off;
-        d.mk_cap = mk_cap;
-        return d;
-    }
-};
 
 // ---------------------------------------------------------------------------------------------
 extern "C" const char* aix_version(void) { return "aindex_hip 0.1.0 (gfx950)"; }
@@ -787,60 +666,85 @@ extern "C" int aix_coverage_batch_dev(aix_index_t* h, const char* d_seqs, const 
 
 static int ensure_count_workspace(aix_index* h, uint64_t need, hipStream_t s);
 
+// K13 in three steps, so that a file can be counted part by part (aix_ingest.hip) as well as in one call: begin() orders the call behind
+// the previous user of the handle's workspace and zeroes the output, add() counts one PLAIN buffer into it (any number of times; every
+// window of the concatenated stream must lie inside exactly one of the buffers), end() finishes the table. The caller holds count_mutex
+// from begin to end.
+int count13_begin_locked(aix_index* h, uint64_t* d_tf_out, hipStream_t s) {
+    // the scratch table / partition workspace belong to the handle: calls are ordered behind one another even when they come
+    // in on different streams (the mutex only orders the enqueueing)
+    if (h->work13_done) HIPCHK(hipStreamWaitEvent(s, h->work13_done, 0));
+    else HIPCHK(hipEventCreateWithFlags(&h->work13_done, hipEventDisableTiming));
+    h->c13_atomics = getenv("AIX_COUNT13_ATOMICS") != nullptr || !h->perm13_bijective;   // env: A/B switch for measurements / tests
+    h->c13_added = false;
+    if (h->c13_atomics) {
+        if (!h->scratch13) {
+            HIPCHK(hipMalloc((void**)&h->scratch13, 8 * AIX_TOTAL_13MERS));
+            h->device_bytes += 8 * AIX_TOTAL_13MERS;
+        }
+        HIPCHK(hipMemsetAsync(h->scratch13, 0, 8 * AIX_TOTAL_13MERS, s));
+    }
+    HIPCHK(hipMemsetAsync(d_tf_out, 0, 8 * AIX_TOTAL_13MERS, s));
+    return AIX_OK;
+}
+
+int count13_add_locked(aix_index* h, const char* d_plain, uint64_t len, uint64_t* d_tf_out, hipStream_t s) {
+    if (h->c13_atomics) {
+        // scattered u64 memory-side atomics into the code-ordered table (slower; kept as the independent cross-check)
+        HIPCHK(launch_count13_plain((const uint8_t*)d_plain, len, h->scratch13, s));
+        h->c13_added = true;
+        return AIX_OK;
+    }
+    // The partitioned path indexes windows and chunks with 32 bits: buffers are cut into pieces of at most `piece` (2^31) window starts.
+    // A window belongs to the piece that holds its first byte; a piece is handed its 12 following bytes as well, so the
+    // cut needs no record boundary and every window is counted exactly once. Pieces after the first add to the table.
+    uint64_t piece = 1ull << 31;
+    if (const char* e = getenv("AIX_COUNT13_PIECE")) { const uint64_t v = strtoull(e, nullptr, 10); if (v >= 1 && v <= (1ull << 31)) piece = v; }
+    const uint64_t nwin = len >= 13 ? len - 12 : 0;
+    if (nwin == 0) return AIX_OK;
+    for (;;) {                                                               // a workspace that does not fit halves the piece (down to 4096 windows)
+        const uint64_t pw = std::min(nwin, piece);
+        const int stw = ensure_count_workspace(h, count13_workspace_bytes(pw + 12), s);
+        if (stw == AIX_OK) break;
+        if (stw != AIX_ERR_NOMEM || pw <= 4096) return stw;
+        piece = pw / 2;
+    }
+    HIPCHK(hipMemsetAsync(h->work13, 0, 4, s));                               // the error word of the workspace
+    for (uint64_t first = 0; first < nwin; first += piece) {
+        const uint64_t w = std::min(piece, nwin - first);
+        HIPCHK(launch_count13_partitioned((const uint8_t*)d_plain + first, w + 12, h->work13, nullptr, h->perm13, d_tf_out, h->c13_added ? 1 : 0, s));   // fused permutation
+        h->c13_added = true;
+    }
+    // a chunk id outside a workgroup's region would have dropped counts: the kernels raise the error word instead of
+    // staying silent, and the call fails (costs one stream wait per call; the table is complete when this returns)
+    uint32_t dropped = 0;
+    HIPCHK(hipMemcpyAsync(&dropped, h->work13, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (dropped) { set_last_error("count13: chunk region exhausted (partition workspace undersized)"); return AIX_ERR_UNSUPPORTED; }
+    return AIX_OK;
+}
+
+int count13_end_locked(aix_index* h, uint64_t* d_tf_out, hipStream_t s) {
+    int st = AIX_OK;
+    if (h->c13_atomics) {
+        const hipError_t e = launch_scatter13_to_mphf(h->perm13, h->scratch13, d_tf_out, h->perm13_bijective ? 0 : 1, s);
+        if (e != hipSuccess) { set_last_error(std::string("count13 scatter: ") + hipGetErrorString(e)); st = AIX_ERR_HIP; }
+    }
+    (void)hipEventRecord(h->work13_done, s);
+    return st;
+}
+
 extern "C" int aix_count13_dev(aix_index_t* h, const char* d_plain, uint64_t len, uint64_t* d_tf_out, void* stream) {
     if (!h || !d_tf_out || (len && !d_plain)) return AIX_ERR_ARG;
     if (h->k != 13) return AIX_ERR_MODE;
     DevGuard g(h->device);
     std::lock_guard<std::mutex> lk(h->count_mutex);
     hipStream_t s = (hipStream_t)stream;
-    // the scratch table / partition workspace belong to the handle: calls are ordered behind one another even when they come
-    // in on different streams (the mutex only orders the enqueueing)
-    if (h->work13_done) HIPCHK(hipStreamWaitEvent(s, h->work13_done, 0));
-    else HIPCHK(hipEventCreateWithFlags(&h->work13_done, hipEventDisableTiming));
-    struct RecordOnExit {
-        hipEvent_t ev; hipStream_t st;
-        ~RecordOnExit() { (void)hipEventRecord(ev, st); }
-    } record_on_exit{h->work13_done, s};
-    const bool use_atomics = getenv("AIX_COUNT13_ATOMICS") != nullptr || !h->perm13_bijective;   // env: A/B switch for measurements / tests
-    if (use_atomics) {
-        if (!h->scratch13) {
-            HIPCHK(hipMalloc((void**)&h->scratch13, 8 * AIX_TOTAL_13MERS));
-            h->device_bytes += 8 * AIX_TOTAL_13MERS;
-        }
-        // scattered u64 memory-side atomics into the code-ordered table (slower; kept as the independent cross-check)
-        HIPCHK(hipMemsetAsync(h->scratch13, 0, 8 * AIX_TOTAL_13MERS, s));
-        HIPCHK(launch_count13_plain((const uint8_t*)d_plain, len, h->scratch13, s));
-    } else {
-        // The partitioned path indexes windows and chunks with 32 bits: buffers are cut into pieces of at most `piece` (2^31) window starts.
-        // A window belongs to the piece that holds its first byte; a piece is handed its 12 following bytes as well, so the
-        // cut needs no record boundary and every window is counted exactly once. Pieces after the first add to the table.
-        uint64_t piece = 1ull << 31;
-        if (const char* e = getenv("AIX_COUNT13_PIECE")) { const uint64_t v = strtoull(e, nullptr, 10); if (v >= 1 && v <= (1ull << 31)) piece = v; }
-        const uint64_t nwin = len >= 13 ? len - 12 : 0;
-        for (;;) {                                                               // a workspace that does not fit halves the piece (down to 4096 windows)
-            const uint64_t pw = std::min(nwin, piece);
-            const int stw = ensure_count_workspace(h, count13_workspace_bytes(pw + 12), s);
-            if (stw == AIX_OK) break;
-            if (stw != AIX_ERR_NOMEM || pw <= 4096) return stw;
-            piece = pw / 2;
-        }
-        HIPCHK(hipMemsetAsync(d_tf_out, 0, 8 * AIX_TOTAL_13MERS, s));
-        HIPCHK(hipMemsetAsync(h->work13, 0, 4, s));                               // the error word of the workspace
-        for (uint64_t first = 0; first < nwin; first += piece) {
-            const uint64_t w = std::min(piece, nwin - first);
-            HIPCHK(launch_count13_partitioned((const uint8_t*)d_plain + first, w + 12, h->work13, nullptr, h->perm13, d_tf_out, first != 0, s));   // fused permutation
-        }
-        // a chunk id outside a workgroup's region would have dropped counts: the kernels raise the error word instead of
-        // staying silent, and the call fails (costs one stream wait per call; the table is complete when this returns)
-        uint32_t dropped = 0;
-        HIPCHK(hipMemcpyAsync(&dropped, h->work13, 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        if (dropped) { set_last_error("count13: chunk region exhausted (partition workspace undersized)"); return AIX_ERR_UNSUPPORTED; }
-        return AIX_OK;
-    }
-    HIPCHK(hipMemsetAsync(d_tf_out, 0, 8 * AIX_TOTAL_13MERS, s));
-    HIPCHK(launch_scatter13_to_mphf(h->perm13, h->scratch13, d_tf_out, h->perm13_bijective ? 0 : 1, s));
-    return AIX_OK;
+    int st = count13_begin_locked(h, d_tf_out, s);
+    if (st) return st;
+    st = count13_add_locked(h, d_plain, len, d_tf_out, s);
+    const int st2 = count13_end_locked(h, d_tf_out, s);
+    return st ? st : st2;
 }
 
 // grow-only per-handle workspace of the counting paths (13-mer partitions; 23-mer slot stream + partitions). Calls are ordered
@@ -1424,60 +1328,20 @@ extern "C" int aix_normalize_reads_dev(const char* d_raw, uint64_t len, int form
     return AIX_OK;
 }
 
-// host buffer -> PLAIN form in HBM: raw bytes go up as they are, FASTA/FASTQ records are normalised on the device
-static int stage_plain(aix_index_t* h, const char* buf, uint64_t len, int format, int fasta_mode, DevBuf& d, uint64_t& plain_len) {
-    (void)h;
-    if (format == AIX_FMT_AUTO) format = aix_detect_format(buf, len);
-    plain_len = len;
-    if (format == AIX_FMT_PLAIN || len == 0) {
-        HIPCHK(d.alloc(len + 8));
-        if (len) HIPCHK(hipMemcpy(d.p, buf, len, hipMemcpyHostToDevice));
-        return AIX_OK;
-    }
-    DevBuf raw;
-    HIPCHK(raw.alloc(len + 8));
-    HIPCHK(hipMemcpy(raw.p, buf, len, hipMemcpyHostToDevice));
-    HIPCHK(d.alloc(len + 16));
-    return aix_normalize_reads_dev((const char*)raw.p, len, format, fasta_mode, (char*)d.p, &plain_len, nullptr);
-}
-
-extern "C" int aix_count13(aix_index_t* h, const char* buf, uint64_t len, int format, uint64_t* tf_out) {
-    if (!h || !tf_out || (len && !buf)) return AIX_ERR_ARG;
-    if (h->k != 13) return AIX_ERR_MODE;
-    DevGuard g(h->device);
-    DevBuf d, dout;
-    uint64_t plen = 0;
-    int st = stage_plain(h, buf, len, format, 0, d, plen);
-    if (st) return st;
-    HIPCHK(dout.alloc(8 * AIX_TOTAL_13MERS));
-    st = aix_count13_dev(h, (const char*)d.p, plen, (uint64_t*)dout.p, nullptr);
-    if (st) return st;
-    HIPCHK(hipStreamSynchronize(0));
-    HIPCHK(hipMemcpy(tf_out, dout.p, 8 * AIX_TOTAL_13MERS, hipMemcpyDeviceToHost));
-    return AIX_OK;
-}
-
-extern "C" int aix_count23_fixed(aix_index_t* h, const char* buf, uint64_t len, int format, int canon_mode, uint32_t* tf_out) {
-    if (!h || !tf_out || (len && !buf)) return AIX_ERR_ARG;
-    if (h->k != 23) return AIX_ERR_MODE;
-    if (h->n == 0) return AIX_OK;
-    DevGuard g(h->device);
-    DevBuf d, dout;
-    uint64_t plen = 0;
-    int st = stage_plain(h, buf, len, format, 1, d, plen);
-    if (st) return st;
-    HIPCHK(dout.alloc(4 * h->n));
-    HIPCHK(hipMemset(dout.p, 0, 4 * h->n));
-    st = aix_count23_fixed_dev(h, (const char*)d.p, plen, canon_mode, (uint32_t*)dout.p, nullptr);
-    if (st) return st;
-    HIPCHK(hipStreamSynchronize(0));
-    HIPCHK(hipMemcpy(tf_out, dout.p, 4 * h->n, hipMemcpyDeviceToHost));
-    return AIX_OK;
-}
-
 // ---------------------------------------------------------------------------------------------
 // A1/A2: positions index
 // ---------------------------------------------------------------------------------------------
+// host buffer -> HBM through the pinned, multi-threaded staging pipeline (aix_ingest.hip); returns when the bytes are on the device
+static int upload_host(const char* buf, uint64_t len, uint8_t* d_dst, int device) {
+    if (len == 0) return AIX_OK;
+    ByteSource src;
+    src.set_memory(buf, len);
+    const int st = upload_pipelined(src, d_dst, device, 0);
+    if (st) return st;
+    HIPCHK(hipStreamSynchronize(0));
+    return AIX_OK;
+}
+
 // first window the reference's single worker looks at (hash.cpp:973-986): the start is pushed past any
 // '\n', '~' or '?' found in the first k bytes, repeatedly
 static uint64_t a2_start(const char* c, uint64_t len, uint64_t k = 23) {
@@ -1513,8 +1377,8 @@ extern "C" int aix_positions_fill(aix_index_t* h, const char* reads, uint64_t le
     DevBuf dreads, dpos;
     HIPCHK(dreads.alloc(len + 8));
     HIPCHK(dpos.alloc(8 * total));
-    if (len) HIPCHK(hipMemcpy(dreads.p, reads, len, hipMemcpyHostToDevice));
-    HIPCHK(hipMemset(dpos.p, 0, 8 * total));
+    HIPCHK(hipMemsetAsync(dpos.p, 0, 8 * total, 0));
+    { const int us = upload_host(reads, len, (uint8_t*)dreads.p, h->device); if (us) return us; }
     HIPCHK(positions_fill(h->dev_slots(), (const uint8_t*)dreads.p, len, a2_start(reads, len, h->k), (const uint64_t*)dind.p, (uint64_t*)dpos.p, piece, nullptr, 0, 0));
     HIPCHK(hipMemcpy(positions_out, dpos.p, 8 * total, hipMemcpyDeviceToHost));
     return AIX_OK;
@@ -1575,7 +1439,7 @@ extern "C" int aix_positions_bucket_counts(aix_index_t* h, const char* reads, ui
     DevBuf dreads, dcnt;
     HIPCHK(dreads.alloc(len + 8));
     HIPCHK(dcnt.alloc(8 * n));
-    if (len) HIPCHK(hipMemcpy(dreads.p, reads, len, hipMemcpyHostToDevice));
+    { const int us = upload_host(reads, len, (uint8_t*)dreads.p, h->device); if (us) return us; }
     HIPCHK(hipMemset(dcnt.p, 0, 8 * n));
     HIPCHK(positions_bucket_counts(h->dev_slots(), (const uint8_t*)dreads.p, len, first_shard ? a2_start(reads, len, h->k) : 0, (unsigned long long*)dcnt.p, 0));
     HIPCHK(hipMemcpy(counts_out, dcnt.p, 8 * n, hipMemcpyDeviceToHost));
@@ -1603,7 +1467,7 @@ extern "C" int aix_positions_fill_shard(aix_index_t* h, const char* reads, uint6
         HIPCHK(dfill.alloc(4 * n));
         HIPCHK(hipMemcpy(dfill.p, filled_init, 4 * n, hipMemcpyHostToDevice));
     }
-    if (len) HIPCHK(hipMemcpy(dreads.p, reads, len, hipMemcpyHostToDevice));
+    { const int us = upload_host(reads, len, (uint8_t*)dreads.p, h->device); if (us) return us; }
     HIPCHK(hipMemset(dpos.p, 0, 8 * total));
     HIPCHK(positions_fill(h->dev_slots(), (const uint8_t*)dreads.p, len, first_shard ? a2_start(reads, len, h->k) : 0, (const uint64_t*)dind.p, (uint64_t*)dpos.p, piece,
                           filled_init ? (const uint32_t*)dfill.p : nullptr, base_offset, 0));
@@ -1695,7 +1559,26 @@ extern "C" int aix_merge_counts_dev(const uint64_t* d_keys, const uint64_t* d_co
     if (!r) return AIX_ERR_NOMEM;
     r->device = device;
     hipError_t e = merge_counts(d_keys, d_counts, n, min_count ? min_count : 1, &r->keys, &r->counts, &r->n, (hipStream_t)stream);
-    if (e != hipSuccess) { delete r; set_last_error(std::string("merge_counts: ") + hipGetErrorString(e)); return e == hipErrorInvalidValue ? AIX_ERR_UNSUPPORTED : AIX_ERR_HIP; }
+    if (e != hipSuccess) { delete r; set_last_error(std::string("merge_counts: ") + hipGetErrorString(e)); return AIX_ERR_HIP; }
+    *out = r;
+    return AIX_OK;
+}
+// the same when the caller knows its runs: run r = entries [run_offsets[r], run_offsets[r + 1]), each sorted by key and free of repeats
+// (after the K1 exchange a rank holds one such run per peer): a tree of two-way merges, nothing is sorted
+extern "C" int aix_merge_runs_dev(const uint64_t* d_keys, const uint64_t* d_counts, const uint64_t* run_offsets, uint32_t nruns, uint64_t min_count, int device,
+                                  void* stream, aix_distinct_t** out) {
+    if (!out || !run_offsets || nruns == 0) return AIX_ERR_ARG;
+    *out = nullptr;
+    for (uint32_t r = 0; r < nruns; ++r) if (run_offsets[r + 1] < run_offsets[r]) return AIX_ERR_ARG;
+    if (run_offsets[nruns] > run_offsets[0] && (!d_keys || !d_counts)) return AIX_ERR_ARG;
+    int st = check_device(device);
+    if (st) return st;
+    DevGuard g(device);
+    aix_distinct* r = new (std::nothrow) aix_distinct();
+    if (!r) return AIX_ERR_NOMEM;
+    r->device = device;
+    hipError_t e = merge_runs(d_keys, d_counts, run_offsets, nruns, min_count ? min_count : 1, &r->keys, &r->counts, &r->n, (hipStream_t)stream);
+    if (e != hipSuccess) { delete r; set_last_error(std::string("merge_runs: ") + hipGetErrorString(e)); return AIX_ERR_HIP; }
     *out = r;
     return AIX_OK;
 }
@@ -1720,35 +1603,4 @@ extern "C" void aix_distinct_free(aix_distinct_t* r) {
     if (r->keys) pool_free(r->keys);
     if (r->counts) pool_free(r->counts);
     delete r;
-}
-
-extern "C" int aix_count_distinct(const char* buf, uint64_t len, int format, int k, int canon_mode, uint64_t min_count, int device, uint64_t** keys_out,
-                                  uint64_t** counts_out, uint64_t* n_out) {
-    if (!keys_out || !counts_out || !n_out || (len && !buf) || k < 1 || k > 31 || canon_mode < 0 || canon_mode > 2) return AIX_ERR_ARG;
-    *keys_out = nullptr; *counts_out = nullptr; *n_out = 0;
-    int st = check_device(device);
-    if (st) return st;
-    DevGuard g(device);
-    DevBuf d;
-    uint64_t plen = 0;
-    st = stage_plain(nullptr, buf, len, format, 1, d, plen);
-    if (st) return st;
-    if (plen < (uint64_t)k) return AIX_OK;
-    uint64_t piece = 0;                                                        // 0: default (2^31 windows per sort)
-    if (const char* e = getenv("AIX_DISTINCT_PIECE")) piece = strtoull(e, nullptr, 10);   // test hook: exercise the merge at small sizes
-    uint64_t *dk = nullptr, *dc = nullptr, m = 0;
-    HIPCHK(distinct_from_plain((const uint8_t*)d.p, plen, k, canon_mode, min_count ? min_count : 1, piece, &dk, &dc, &m, 0));
-    uint64_t* hk = (uint64_t*)malloc(8 * (m ? m : 1));
-    uint64_t* hc = (uint64_t*)malloc(8 * (m ? m : 1));
-    hipError_t e = hipSuccess;
-    if (!hk || !hc) { free(hk); free(hc); if (dk) pool_free(dk); if (dc) pool_free(dc); return AIX_ERR_NOMEM; }
-    if (m) {
-        e = hipMemcpy(hk, dk, 8 * m, hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(hc, dc, 8 * m, hipMemcpyDeviceToHost);
-    }
-    if (dk) pool_free(dk);
-    if (dc) pool_free(dc);
-    if (e != hipSuccess) { free(hk); free(hc); set_last_error(std::string("count_distinct: ") + hipGetErrorString(e)); return AIX_ERR_HIP; }
-    *keys_out = hk; *counts_out = hc; *n_out = m;
-    return AIX_OK;
 }

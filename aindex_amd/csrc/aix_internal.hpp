@@ -116,8 +116,48 @@ hipError_t distinct_from_plain(const uint8_t* d_plain, uint64_t plen, int k, int
 hipError_t merge_counts(const uint64_t* d_keys, const uint64_t* d_counts, uint64_t n, uint64_t min_count, uint64_t** d_keys_out, uint64_t** d_counts_out,
                         uint64_t* n_out, hipStream_t s);
 
+// sorted (key, count) runs merged without a sort (aix_merge.hip)
+struct DevArr {                       // RAII holder of a pool block used on stream `st`: the stream is synchronised before the block goes back
+    void* p = nullptr;
+    hipStream_t st = nullptr;
+    DevArr() = default;
+    explicit DevArr(hipStream_t s) : st(s) {}
+    DevArr(const DevArr&) = delete;
+    DevArr& operator=(const DevArr&) = delete;
+    void drop() { if (p) { (void)hipStreamSynchronize(st); pool_free(p); p = nullptr; } }
+    ~DevArr() { drop(); }
+    hipError_t alloc(size_t bytes) { drop(); return pool_alloc(&p, bytes ? bytes : 1); }
+    void* release() { void* q = p; p = nullptr; return q; }
+};
+hipError_t merge_sum_runs(const uint64_t* ak, const uint64_t* ac, uint64_t na, const uint64_t* bk, const uint64_t* bc, uint64_t nb, uint64_t** d_keys_out,
+                          uint64_t** d_counts_out, uint64_t* n_out, hipStream_t s);
+hipError_t merge_runs(const uint64_t* d_keys, const uint64_t* d_counts, const uint64_t* offs /* host, nruns + 1 */, uint32_t nruns, uint64_t min_count,
+                      uint64_t** d_keys_out, uint64_t** d_counts_out, uint64_t* n_out, hipStream_t s);
+// the distinct k-mers of everything added so far; a piece = all k-windows of one PLAIN buffer (<= 2^31 windows)
+class DistinctAcc {
+public:
+    DistinctAcc(int k, int canon_mode, hipStream_t s);
+    ~DistinctAcc();
+    DistinctAcc(const DistinctAcc&) = delete;
+    DistinctAcc& operator=(const DistinctAcc&) = delete;
+    hipError_t add_plain(const uint8_t* d_plain, uint64_t plen);
+    hipError_t finish(uint64_t min_count, uint64_t** d_keys_out, uint64_t** d_counts_out, uint64_t* n_out);   // pool blocks, the caller frees
+    uint64_t size() const { return acc_n; }
+    uint64_t pieces = 0, merges = 0;
+private:
+    int k, canon_mode;
+    hipStream_t s;
+    uint64_t* acc_k = nullptr;
+    uint64_t* acc_c = nullptr;
+    uint64_t acc_n = 0;
+};
+
 // record normalisation on the device (aix_normalize.hip); d_out holds len + 1 bytes
 hipError_t normalise_device(const uint8_t* d_raw, uint64_t len, int format, int fasta_mode, uint8_t* d_out, uint64_t* out_len, hipStream_t s);
+// one part of an input normalised piece by piece: *state_io = reader state handed from part to part (AIX_NORM_START before the first)
+static constexpr uint32_t AIX_NORM_START = 0xFFFFFFFFu;
+hipError_t normalise_device_part(const uint8_t* d_raw, uint64_t len, int format, int fasta_mode, uint8_t* d_out, uint64_t* out_len, uint32_t* state_io, int last,
+                                 hipStream_t s);
 
 // synthetic generators
 hipError_t launch_synth_genome(uint64_t seed, uint64_t length, uint8_t* out, hipStream_t s);

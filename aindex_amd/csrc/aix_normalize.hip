@@ -169,7 +169,8 @@ __global__ void __launch_bounds__(NTB) k_norm_pick(const ChunkSummary* __restric
 
 template <int KIND>
 __global__ void __launch_bounds__(NTB) k_norm_emit(const uint8_t* __restrict__ raw, uint64_t len, uint64_t nchunks, const uint8_t* __restrict__ start_state,
-                                                  const uint64_t* __restrict__ offs, uint8_t* __restrict__ out, uint64_t* __restrict__ out_len) {
+                                                  const uint64_t* __restrict__ offs, uint8_t* __restrict__ out, uint64_t* __restrict__ out_len /* [0] length, [1] end state */,
+                                                  int last) {
     const uint64_t c = (uint64_t)blockIdx.x * NTB + threadIdx.x;
     if (c >= nchunks) return;
     const uint64_t lo = c * NCH;
@@ -190,70 +191,104 @@ __global__ void __launch_bounds__(NTB) k_norm_emit(const uint8_t* __restrict__ r
     }
     for (uint32_t k = 0; k < have; ++k) out[w++] = (uint8_t)(acc >> (8 * k));
     if (c == nchunks - 1) {
-        if (norm_final_newline<KIND>(st)) out[w++] = '\n';
-        *out_len = w;
+        if (last && norm_final_newline<KIND>(st)) out[w++] = '\n';     // only the end of the INPUT closes the open record; a part hands its state on
+        out_len[0] = w;
+        out_len[1] = st;
     }
 }
 
+// scratch of one call, from the device-block cache (a 256 MiB part needs ~60 MB; hipMalloc / hipFree per call cost more than the kernels)
+struct NormScratch {
+    void* p = nullptr;
+    ~NormScratch() { if (p) pool_free(p); }
+};
+
 template <int KIND>
-static hipError_t normalise_impl(const uint8_t* d_raw, uint64_t len, uint8_t* d_out, uint64_t* d_out_len, hipStream_t s) {
+static hipError_t normalise_impl(const uint8_t* d_raw, uint64_t len, uint8_t* d_out, uint64_t* d_out_len, uint32_t init, int last, hipStream_t s) {
     const uint64_t nchunks = (len + NCH - 1) / NCH;
-    ChunkSummary* sum = nullptr;
-    uint32_t *funcs = nullptr, *prefix = nullptr;
-    uint8_t* start = nullptr;
-    uint64_t *counts = nullptr, *offs = nullptr;
-    void* tmp = nullptr;
     const unsigned grid = (unsigned)((nchunks + NTB - 1) / NTB);
-    hipError_t e = hipMalloc((void**)&sum, sizeof(ChunkSummary) * nchunks);
-    if (e == hipSuccess) e = hipMalloc((void**)&funcs, 4 * nchunks);
-    if (e == hipSuccess) e = hipMalloc((void**)&prefix, 4 * nchunks);
-    if (e == hipSuccess) e = hipMalloc((void**)&start, nchunks);
-    if (e == hipSuccess) e = hipMalloc((void**)&counts, 8 * nchunks);
-    if (e == hipSuccess) e = hipMalloc((void**)&offs, 8 * nchunks);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_norm_summarise<KIND>, dim3(grid), dim3(NTB), 0, s, d_raw, len, nchunks, sum);
-        hipLaunchKernelGGL(k_norm_funcs, dim3(grid), dim3(NTB), 0, s, sum, nchunks, funcs);
-        e = hipGetLastError();
-    }
+    auto up = [](uint64_t x) { return (x + 255) / 256 * 256; };
     size_t tb = 0, tb2 = 0;
-    if (e == hipSuccess) e = rocprim::exclusive_scan(nullptr, tb, funcs, prefix, kIdentityFunc, (size_t)nchunks, ComposeOp(), s);
-    if (e == hipSuccess) e = rocprim::exclusive_scan(nullptr, tb2, counts, offs, (uint64_t)0, (size_t)nchunks, rocprim::plus<uint64_t>(), s);
+    hipError_t e = rocprim::exclusive_scan(nullptr, tb, (uint32_t*)nullptr, (uint32_t*)nullptr, kIdentityFunc, (size_t)nchunks, ComposeOp(), s);
+    if (e == hipSuccess) e = rocprim::exclusive_scan(nullptr, tb2, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint64_t)0, (size_t)nchunks, rocprim::plus<uint64_t>(), s);
+    if (e != hipSuccess) return e;
     if (tb2 > tb) tb = tb2;
-    if (e == hipSuccess) e = hipMalloc(&tmp, tb ? tb : 1);
+    NormScratch scr;
+    e = pool_alloc(&scr.p, up(sizeof(ChunkSummary) * nchunks) + 2 * up(4 * nchunks) + up(nchunks) + 2 * up(8 * nchunks) + up(tb ? tb : 1));
+    if (e != hipSuccess) return e;
+    uint8_t* w = (uint8_t*)scr.p;
+    ChunkSummary* sum = (ChunkSummary*)w;   w += up(sizeof(ChunkSummary) * nchunks);
+    uint32_t* funcs = (uint32_t*)w;         w += up(4 * nchunks);
+    uint32_t* prefix = (uint32_t*)w;        w += up(4 * nchunks);
+    uint8_t* start = w;                     w += up(nchunks);
+    uint64_t* counts = (uint64_t*)w;        w += up(8 * nchunks);
+    uint64_t* offs = (uint64_t*)w;          w += up(8 * nchunks);
+    void* tmp = w;
+    hipLaunchKernelGGL(k_norm_summarise<KIND>, dim3(grid), dim3(NTB), 0, s, d_raw, len, nchunks, sum);
+    hipLaunchKernelGGL(k_norm_funcs, dim3(grid), dim3(NTB), 0, s, sum, nchunks, funcs);
+    e = hipGetLastError();
     if (e == hipSuccess) e = rocprim::exclusive_scan(tmp, tb, funcs, prefix, kIdentityFunc, (size_t)nchunks, ComposeOp(), s);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_norm_pick, dim3(grid), dim3(NTB), 0, s, sum, prefix, nchunks, norm_initial<KIND>(), start, counts);
+        hipLaunchKernelGGL(k_norm_pick, dim3(grid), dim3(NTB), 0, s, sum, prefix, nchunks, init, start, counts);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = rocprim::exclusive_scan(tmp, tb, counts, offs, (uint64_t)0, (size_t)nchunks, rocprim::plus<uint64_t>(), s);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_norm_emit<KIND>, dim3(grid), dim3(NTB), 0, s, d_raw, len, nchunks, start, offs, d_out, d_out_len);
+        hipLaunchKernelGGL(k_norm_emit<KIND>, dim3(grid), dim3(NTB), 0, s, d_raw, len, nchunks, start, offs, d_out, d_out_len, last);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (tmp) (void)hipFree(tmp);
-    if (sum) (void)hipFree(sum);
-    if (funcs) (void)hipFree(funcs);
-    if (prefix) (void)hipFree(prefix);
-    if (start) (void)hipFree(start);
-    if (counts) (void)hipFree(counts);
-    if (offs) (void)hipFree(offs);
-    return e;
+    const hipError_t e2 = hipStreamSynchronize(s);              // the scratch goes back to the cache idle
+    return e != hipSuccess ? e : e2;
+}
+
+static uint32_t norm_initial_of(int format, int fasta_mode) {
+    if (format == AIX_FMT_FASTQ) return norm_initial<NORM_FASTQ>();
+    return fasta_mode == 0 ? norm_initial<NORM_FASTA13>() : norm_initial<NORM_FASTAK1>();
+}
+
+// One PART of an input that is normalised piece by piece (streaming ingestion): *state_io carries the reader's state from the end of the
+// previous part (AIX_NORM_START before the first one) to the start of this one, so parts may be cut at ANY byte; the concatenation of the
+// parts' outputs is byte for byte the output of one call over the whole input. `last`: this part ends the input (an open record gets its
+// closing '\n'). d_out needs len + 1 bytes.
+hipError_t normalise_device_part(const uint8_t* d_raw, uint64_t len, int format, int fasta_mode, uint8_t* d_out, uint64_t* out_len, uint32_t* state_io, int last,
+                                 hipStream_t s) {
+    *out_len = 0;
+    uint32_t init = (state_io && *state_io != AIX_NORM_START) ? (*state_io & 7u) : norm_initial_of(format, fasta_mode);
+    if (len == 0) {
+        if (state_io) *state_io = init;
+        if (last) {                                              // nothing left to read: only the record still open needs its '\n'
+            bool nl = false;
+            if (format == AIX_FMT_FASTQ) nl = norm_final_newline<NORM_FASTQ>(init);
+            else if (fasta_mode == 0) nl = norm_final_newline<NORM_FASTA13>(init);
+            else nl = norm_final_newline<NORM_FASTAK1>(init);
+            if (nl) {
+                const uint8_t c = '\n';
+                hipError_t e = hipMemcpyAsync(d_out, &c, 1, hipMemcpyHostToDevice, s);
+                if (e == hipSuccess) e = hipStreamSynchronize(s);
+                if (e != hipSuccess) return e;
+                *out_len = 1;
+            }
+        }
+        return hipSuccess;
+    }
+    NormScratch d_len;
+    hipError_t e = pool_alloc(&d_len.p, 16);
+    if (e != hipSuccess) return e;
+    if (format == AIX_FMT_FASTQ) e = normalise_impl<NORM_FASTQ>(d_raw, len, d_out, (uint64_t*)d_len.p, init, last, s);
+    else if (fasta_mode == 0) e = normalise_impl<NORM_FASTA13>(d_raw, len, d_out, (uint64_t*)d_len.p, init, last, s);
+    else e = normalise_impl<NORM_FASTAK1>(d_raw, len, d_out, (uint64_t*)d_len.p, init, last, s);
+    uint64_t res[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpy(res, d_len.p, 16, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return e;
+    *out_len = res[0];
+    if (state_io) *state_io = (uint32_t)res[1];
+    return hipSuccess;
 }
 
 // d_out needs len + 1 bytes. *out_len (host) receives the normalised length. format: AIX_FMT_FASTA / AIX_FMT_FASTQ.
 hipError_t normalise_device(const uint8_t* d_raw, uint64_t len, int format, int fasta_mode, uint8_t* d_out, uint64_t* out_len, hipStream_t s) {
-    *out_len = 0;
-    if (len == 0) return hipSuccess;
-    uint64_t* d_len = nullptr;
-    hipError_t e = hipMalloc((void**)&d_len, 8);
-    if (e != hipSuccess) return e;
-    if (format == AIX_FMT_FASTQ) e = normalise_impl<NORM_FASTQ>(d_raw, len, d_out, d_len, s);
-    else if (fasta_mode == 0) e = normalise_impl<NORM_FASTA13>(d_raw, len, d_out, d_len, s);
-    else e = normalise_impl<NORM_FASTAK1>(d_raw, len, d_out, d_len, s);
-    if (e == hipSuccess) e = hipMemcpy(out_len, d_len, 8, hipMemcpyDeviceToHost);
-    (void)hipFree(d_len);
-    return e;
+    uint32_t st = AIX_NORM_START;
+    return normalise_device_part(d_raw, len, format, fasta_mode, d_out, out_len, &st, 1, s);
 }
 
 }  // namespace aix

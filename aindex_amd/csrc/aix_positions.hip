@@ -354,170 +354,4 @@ hipError_t distinct_from_codes(uint64_t* d_codes /* clobbered */, uint64_t nwin,
     return hipSuccess;
 }
 
-// ---------------------------------------------------------------------------------------------
-// K1 for buffers of any length: the windows are counted piece by piece (a window belongs to the piece that holds its
-// first byte; a piece is handed the k-1 bytes behind it), the distinct sets of the pieces are merged by sort +
-// reduce-by-key with 64-bit counts, and min_count applies to the merged counts.
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(kB) k_widen_counts(const uint32_t* __restrict__ c32, uint64_t n, uint64_t* __restrict__ c64) {
-    const uint64_t stride = (uint64_t)gridDim.x * kB;
-    for (uint64_t i = (uint64_t)blockIdx.x * kB + threadIdx.x; i < n; i += stride) c64[i] = c32[i];
-}
-__global__ void __launch_bounds__(kB) k_flag_min64(const uint64_t* __restrict__ counts, uint64_t n, uint64_t min_count, uint8_t* __restrict__ flags) {
-    const uint64_t stride = (uint64_t)gridDim.x * kB;
-    for (uint64_t i = (uint64_t)blockIdx.x * kB + threadIdx.x; i < n; i += stride) flags[i] = counts[i] >= min_count ? 1 : 0;
-}
-
-struct DevArr {                       // RAII holder of a pool block used on stream `st`: the stream is synchronised before the block goes back
-    void* p = nullptr;
-    hipStream_t st = nullptr;
-    DevArr() = default;
-    explicit DevArr(hipStream_t s) : st(s) {}
-    void drop() { if (p) { (void)hipStreamSynchronize(st); pool_free(p); p = nullptr; } }
-    ~DevArr() { drop(); }
-    hipError_t alloc(size_t bytes) { drop(); return pool_alloc(&p, bytes ? bytes : 1); }
-    void* release() { void* q = p; p = nullptr; return q; }
-};
-
-hipError_t distinct_from_plain(const uint8_t* d_plain, uint64_t plen, int k, int canon_mode, uint64_t min_count, uint64_t piece, uint64_t** d_keys_out,
-                               uint64_t** d_counts_out, uint64_t* n_out, hipStream_t s) {
-    *d_keys_out = nullptr; *d_counts_out = nullptr; *n_out = 0;
-    if (plen < (uint64_t)k) return hipSuccess;
-    const uint64_t nwin_all = plen - k + 1;
-    if (piece == 0 || piece > (1ull << 31)) piece = 1ull << 31;              // rocPRIM's run-length encode takes a 32-bit size
-    DevArr acc_k(s), acc_c(s);                                                // merged distinct set so far
-    uint64_t acc_n = 0;
-    hipError_t e = hipSuccess;
-    for (uint64_t w0 = 0; e == hipSuccess && w0 < nwin_all; w0 += piece) {
-        const uint64_t nwin = std::min(piece, nwin_all - w0);
-        DevArr codes(s);
-        e = codes.alloc(8 * nwin);
-        uint64_t* pk = nullptr; uint32_t* pc = nullptr; uint64_t pm = 0;
-        uint64_t* pc64 = nullptr;                                             // the MSD path hands its counts over as u64 (no widening pass)
-        bool sorted_path = !k1_msd_eligible(nwin, k);
-        if (e == hipSuccess && sorted_path) e = launch_window_codes(d_plain + w0, nwin + k - 1, k, canon_mode, (uint64_t*)codes.p, s);
-        if (e == hipSuccess && !sorted_path) {                                // MSD partition + per-bucket LDS hash / sort (aix_k1.hip); windows encoded inside level 1
-            bool fell_back = false;
-            e = distinct_from_codes_msd((uint64_t*)codes.p, nwin, k, &pk, &pc, &pm, &fell_back, s, d_plain + w0, nwin + k - 1, canon_mode, &pc64);
-            if (e == hipSuccess && fell_back) {                               // a bucket too rich for LDS: the codes were used as staging, make them again
-                sorted_path = true;
-                e = launch_window_codes(d_plain + w0, nwin + k - 1, k, canon_mode, (uint64_t*)codes.p, s);
-            }
-        }
-        if (e == hipSuccess && sorted_path) e = distinct_from_codes((uint64_t*)codes.p, nwin, k, 1, &pk, &pc, &pm, s);
-        DevArr hold_k(s), hold_c(s), hold_c64(s); hold_k.p = pk; hold_c.p = pc; hold_c64.p = pc64;
-        if (e != hipSuccess || pm == 0) continue;
-        if (acc_n == 0 && pc64) {                                             // first non-empty piece from the MSD path: sorted, distinct, u64 counts — taken as it is
-            acc_k.p = hold_k.release(); acc_c.p = hold_c64.release(); acc_n = pm;
-            continue;
-        }
-        // concatenate {acc, piece} as (key, u64 count), sort by key, sum equal keys
-        const uint64_t tot = acc_n + pm;
-        if (tot >> 32) { e = hipErrorInvalidValue; continue; }                // rocPRIM reduce_by_key takes a 32-bit size: < 2^32 distinct k-mers
-        DevArr cat_k(s), cat_c(s), srt_k(s), srt_c(s), out_k(s), out_c(s), d_n(s), tmp(s);
-        e = cat_k.alloc(8 * tot);
-        if (e == hipSuccess) e = cat_c.alloc(8 * tot);
-        if (e == hipSuccess && acc_n) e = hipMemcpyAsync(cat_k.p, acc_k.p, 8 * acc_n, hipMemcpyDeviceToDevice, s);
-        if (e == hipSuccess && acc_n) e = hipMemcpyAsync(cat_c.p, acc_c.p, 8 * acc_n, hipMemcpyDeviceToDevice, s);
-        if (e == hipSuccess) e = hipMemcpyAsync((uint64_t*)cat_k.p + acc_n, pk, 8 * pm, hipMemcpyDeviceToDevice, s);
-        if (e == hipSuccess && pc64) e = hipMemcpyAsync((uint64_t*)cat_c.p + acc_n, pc64, 8 * pm, hipMemcpyDeviceToDevice, s);
-        if (e == hipSuccess && !pc64) { hipLaunchKernelGGL(k_widen_counts, dim3(grid_of(pm)), dim3(kB), 0, s, pc, pm, (uint64_t*)cat_c.p + acc_n); e = hipGetLastError(); }
-        if (e == hipSuccess && acc_n == 0) {                                  // first non-empty piece: already sorted and distinct
-            (void)hipStreamSynchronize(s);
-            acc_k.p = cat_k.release(); acc_c.p = cat_c.release(); acc_n = tot;
-            continue;
-        }
-        if (e == hipSuccess) e = srt_k.alloc(8 * tot);
-        if (e == hipSuccess) e = srt_c.alloc(8 * tot);
-        size_t tb = 0;
-        if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, tb, (uint64_t*)cat_k.p, (uint64_t*)srt_k.p, (uint64_t*)cat_c.p, (uint64_t*)srt_c.p, (size_t)tot, 0u, (unsigned)(2 * k), s);
-        if (e == hipSuccess) e = tmp.alloc(tb);
-        if (e == hipSuccess) e = rocprim::radix_sort_pairs(tmp.p, tb, (uint64_t*)cat_k.p, (uint64_t*)srt_k.p, (uint64_t*)cat_c.p, (uint64_t*)srt_c.p, (size_t)tot, 0u, (unsigned)(2 * k), s);
-        if (e == hipSuccess) e = out_k.alloc(8 * tot);
-        if (e == hipSuccess) e = out_c.alloc(8 * tot);
-        if (e == hipSuccess) e = d_n.alloc(8);
-        tb = 0;
-        if (e == hipSuccess) e = rocprim::reduce_by_key(nullptr, tb, (uint64_t*)srt_k.p, (uint64_t*)srt_c.p, (unsigned int)tot, (uint64_t*)out_k.p, (uint64_t*)out_c.p, (uint64_t*)d_n.p, rocprim::plus<uint64_t>(), rocprim::equal_to<uint64_t>(), s);
-        if (e == hipSuccess) { (void)hipStreamSynchronize(s); e = tmp.alloc(tb); }
-        if (e == hipSuccess) e = rocprim::reduce_by_key(tmp.p, tb, (uint64_t*)srt_k.p, (uint64_t*)srt_c.p, (unsigned int)tot, (uint64_t*)out_k.p, (uint64_t*)out_c.p, (uint64_t*)d_n.p, rocprim::plus<uint64_t>(), rocprim::equal_to<uint64_t>(), s);
-        uint64_t merged = 0;
-        if (e == hipSuccess) e = hipMemcpyAsync(&merged, d_n.p, 8, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e == hipSuccess) {
-            if (acc_k.p) pool_free(acc_k.p);
-            if (acc_c.p) pool_free(acc_c.p);
-            acc_k.p = out_k.release(); acc_c.p = out_c.release(); acc_n = merged;
-        }
-    }
-    if (e != hipSuccess) return e;
-    if (acc_n == 0) return hipSuccess;
-    if (min_count > 1) {
-        DevArr flags(s), fk(s), fc(s), d_sel(s), tmp(s);
-        e = flags.alloc(acc_n);
-        if (e == hipSuccess) e = fk.alloc(8 * acc_n);
-        if (e == hipSuccess) e = fc.alloc(8 * acc_n);
-        if (e == hipSuccess) e = d_sel.alloc(8);
-        size_t tb = 0;
-        if (e == hipSuccess) { hipLaunchKernelGGL(k_flag_min64, dim3(grid_of(acc_n)), dim3(kB), 0, s, (const uint64_t*)acc_c.p, acc_n, min_count, (uint8_t*)flags.p); e = hipGetLastError(); }
-        if (e == hipSuccess) e = rocprim::select(nullptr, tb, (uint64_t*)acc_k.p, (uint8_t*)flags.p, (uint64_t*)fk.p, (uint64_t*)d_sel.p, (size_t)acc_n, s);
-        if (e == hipSuccess) e = tmp.alloc(tb);
-        if (e == hipSuccess) e = rocprim::select(tmp.p, tb, (uint64_t*)acc_k.p, (uint8_t*)flags.p, (uint64_t*)fk.p, (uint64_t*)d_sel.p, (size_t)acc_n, s);
-        if (e == hipSuccess) e = rocprim::select(tmp.p, tb, (uint64_t*)acc_c.p, (uint8_t*)flags.p, (uint64_t*)fc.p, (uint64_t*)d_sel.p, (size_t)acc_n, s);
-        uint64_t kept = 0;
-        if (e == hipSuccess) e = hipMemcpyAsync(&kept, d_sel.p, 8, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e != hipSuccess) return e;
-        *d_keys_out = (uint64_t*)fk.release(); *d_counts_out = (uint64_t*)fc.release(); *n_out = kept;
-        return hipSuccess;
-    }
-    *d_keys_out = (uint64_t*)acc_k.release(); *d_counts_out = (uint64_t*)acc_c.release(); *n_out = acc_n;
-    return hipSuccess;
-}
-
-// (key, count) pairs with repeated keys (the shares of several ranks after the K1 exchange) -> keys ascending, counts summed,
-// counts >= min_count. Inputs are not modified.
-hipError_t merge_counts(const uint64_t* d_keys, const uint64_t* d_counts, uint64_t n, uint64_t min_count, uint64_t** d_keys_out, uint64_t** d_counts_out,
-                        uint64_t* n_out, hipStream_t s) {
-    *d_keys_out = nullptr; *d_counts_out = nullptr; *n_out = 0;
-    if (n == 0) return hipSuccess;
-    if (n >> 32) return hipErrorInvalidValue;
-    DevArr srt_k(s), srt_c(s), out_k(s), out_c(s), d_n(s), tmp(s), flags(s), fk(s), fc(s);
-    hipError_t e = srt_k.alloc(8 * n);
-    if (e == hipSuccess) e = srt_c.alloc(8 * n);
-    size_t tb = 0;
-    if (e == hipSuccess) e = rocprim::radix_sort_pairs(nullptr, tb, d_keys, (uint64_t*)srt_k.p, d_counts, (uint64_t*)srt_c.p, (size_t)n, 0u, 64u, s);
-    if (e == hipSuccess) e = tmp.alloc(tb);
-    if (e == hipSuccess) e = rocprim::radix_sort_pairs(tmp.p, tb, d_keys, (uint64_t*)srt_k.p, d_counts, (uint64_t*)srt_c.p, (size_t)n, 0u, 64u, s);
-    if (e == hipSuccess) e = out_k.alloc(8 * n);
-    if (e == hipSuccess) e = out_c.alloc(8 * n);
-    if (e == hipSuccess) e = d_n.alloc(8);
-    tb = 0;
-    if (e == hipSuccess) e = rocprim::reduce_by_key(nullptr, tb, (uint64_t*)srt_k.p, (uint64_t*)srt_c.p, (unsigned int)n, (uint64_t*)out_k.p, (uint64_t*)out_c.p, (uint64_t*)d_n.p, rocprim::plus<uint64_t>(), rocprim::equal_to<uint64_t>(), s);
-    if (e == hipSuccess) e = tmp.alloc(tb);
-    if (e == hipSuccess) e = rocprim::reduce_by_key(tmp.p, tb, (uint64_t*)srt_k.p, (uint64_t*)srt_c.p, (unsigned int)n, (uint64_t*)out_k.p, (uint64_t*)out_c.p, (uint64_t*)d_n.p, rocprim::plus<uint64_t>(), rocprim::equal_to<uint64_t>(), s);
-    uint64_t merged = 0;
-    if (e == hipSuccess) e = hipMemcpyAsync(&merged, d_n.p, 8, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (e != hipSuccess) return e;
-    if (min_count > 1 && merged) {
-        e = flags.alloc(merged);
-        if (e == hipSuccess) e = fk.alloc(8 * merged);
-        if (e == hipSuccess) e = fc.alloc(8 * merged);
-        if (e == hipSuccess) { hipLaunchKernelGGL(k_flag_min64, dim3(grid_of(merged)), dim3(kB), 0, s, (const uint64_t*)out_c.p, merged, min_count, (uint8_t*)flags.p); e = hipGetLastError(); }
-        tb = 0;
-        if (e == hipSuccess) e = rocprim::select(nullptr, tb, (uint64_t*)out_k.p, (uint8_t*)flags.p, (uint64_t*)fk.p, (uint64_t*)d_n.p, (size_t)merged, s);
-        if (e == hipSuccess) e = tmp.alloc(tb);
-        if (e == hipSuccess) e = rocprim::select(tmp.p, tb, (uint64_t*)out_k.p, (uint8_t*)flags.p, (uint64_t*)fk.p, (uint64_t*)d_n.p, (size_t)merged, s);
-        if (e == hipSuccess) e = rocprim::select(tmp.p, tb, (uint64_t*)out_c.p, (uint8_t*)flags.p, (uint64_t*)fc.p, (uint64_t*)d_n.p, (size_t)merged, s);
-        uint64_t kept = 0;
-        if (e == hipSuccess) e = hipMemcpyAsync(&kept, d_n.p, 8, hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e != hipSuccess) return e;
-        *d_keys_out = (uint64_t*)fk.release(); *d_counts_out = (uint64_t*)fc.release(); *n_out = kept;
-        return hipSuccess;
-    }
-    *d_keys_out = (uint64_t*)out_k.release(); *d_counts_out = (uint64_t*)out_c.release(); *n_out = merged;
-    return hipSuccess;
-}
-
 }  // namespace aix

@@ -173,15 +173,19 @@ def _owner_of(keys, world: int):
     return lsr(z, 1) % world                          # non-negative before the modulo
 
 
-def exchange_merge_counts(keys, counts, min_count: int = 1):
+def exchange_merge_counts(keys, counts, min_count: int = 1, keys_sorted: bool = False):
     """One all-to-all of (key, count) pairs: every rank sends each of its locally distinct keys to the key's owner and
     sums what it receives. keys: int64 (u64 bit patterns, any order, distinct per rank), counts: int64.
     Returns this rank's share of the GLOBAL distinct set: (keys ascending, summed counts >= min_count). The shares of
     all ranks are disjoint and their union is the unsharded result. Works on CPU tensors (gloo) and device tensors
-    (nccl = RCCL; with gloo the exchange itself is staged through host memory)."""
+    (nccl = RCCL; with gloo the exchange itself is staged through host memory).
+    keys_sorted: this rank's keys are ascending (what count_distinct_t returns). The stable split by owner then leaves every peer's
+    segment ascending, so the receiver holds one sorted run per peer and merges them (aix_merge_runs_dev: a tree of two-way merges with
+    summation, the reference's single merge of per-thread maps, count_kmers.cpp:334-341) instead of sorting the concatenation."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    run_offsets = [0, int(keys.numel())]
     if world > 1 or (world == 1 and os.environ.get("AIX_FORCE_DIST") and dist.is_initialized()):
         owner = _owner_of(keys, world)
         order = torch.argsort(owner, stable=True)
@@ -199,9 +203,14 @@ def exchange_merge_counts(keys, counts, min_count: int = 1):
         dist.all_to_all_single(rk, keys.to(xdev), output_split_sizes=outs, input_split_sizes=ins)
         dist.all_to_all_single(rc, counts.to(xdev), output_split_sizes=outs, input_split_sizes=ins)
         keys, counts = rk.to(dev), rc.to(dev)
+        run_offsets = [0]
+        for m in outs:
+            run_offsets.append(run_offsets[-1] + int(m))
     # local merge: equal keys from different ranks are summed (keys compare as u64: every valid code is < 2^62)
-    if keys.is_cuda:                                  # product path: sort + reduce-by-key inside the library
-        from .counting import merge_counts_t
+    if keys.is_cuda:                                  # product path, inside the library: merge of the peers' sorted runs, or sort + reduce-by-key
+        from .counting import merge_counts_t, merge_runs_t
+        if keys_sorted:
+            return merge_runs_t(keys, counts, run_offsets, min_count)
         return merge_counts_t(keys, counts, min_count)
     ukeys, inv = torch.unique(keys, sorted=True, return_inverse=True)      # CPU tensors: the gloo tests' plumbing
     sums = torch.zeros(ukeys.numel(), dtype=torch.int64, device=keys.device)
@@ -222,7 +231,7 @@ def count_distinct_sharded(plain: bytes, k: int, canon_mode: int = 2, min_count:
     mine = shard_lines(plain, rank, world)
     t = torch.frombuffer(bytearray(mine) if mine else bytearray(1), dtype=torch.uint8)[: len(mine)].to(f"cuda:{device}")
     keys, counts = counting.count_distinct_t(t, k, canon_mode, 1)
-    return exchange_merge_counts(keys, counts, min_count)
+    return exchange_merge_counts(keys, counts, min_count, keys_sorted=True)
 
 
 def count_distinct_sharded_t(plain_t, k: int, canon_mode: int = 2, min_count: int = 1):
@@ -231,7 +240,7 @@ def count_distinct_sharded_t(plain_t, k: int, canon_mode: int = 2, min_count: in
     (one all-to-all under "nccl"). Returns this rank's share of the global distinct set as device int64 tensors."""
     from . import counting
     keys, counts = counting.count_distinct_t(plain_t, k, canon_mode, 1)
-    return exchange_merge_counts(keys, counts, min_count)
+    return exchange_merge_counts(keys, counts, min_count, keys_sorted=True)
 
 
 def coverage_sharded(index, seqs, cutoff: int = 0):

@@ -8,6 +8,7 @@ All results are bit-exact with the reference's CPU implementation (see tests/).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Sequence, Tuple
 
 import numpy as np
@@ -265,8 +266,25 @@ class Index:
         check(lib().aix_count23_fixed(self._h, _np_ptr(a), a.shape[0], fmt, canon_mode, _np_ptr(out)), "aix_count23_fixed")
         return out
 
-    def positions_fill(self, reads: bytes):
-        """A1 + A2: (indices uint64[n+1], positions uint64[sum tf]) = the .indices.bin / .index.bin images."""
+    def count13_file(self, path: str, out_path: Optional[str] = None, fmt: int = _lib.FMT_AUTO, want_array: bool = True):
+        """count_kmers13 on a FILE, streamed (aix_count13_file: the file is read part by part into pinned staging while the previous part is
+        counted; the host never holds it). Returns (u64[4^13] or None, stats dict); out_path receives the reference's output file."""
+        out = np.empty(_lib.TOTAL_13MERS, dtype=np.uint64) if want_array else None
+        st = _lib.IngestStats()
+        check(lib().aix_count13_file(self._h, os.fsencode(path), fmt, os.fsencode(out_path) if out_path else None, _np_ptr(out), C.byref(st)),
+              f"aix_count13_file({path})")
+        return out, st.as_dict()
+
+    def count23_fixed_file(self, path: str, fmt: int = _lib.FMT_AUTO, canon_mode: int = _lib.CANON_TRUE_RC):
+        """aix_count23_fixed on a FILE, streamed. Returns (u32[n], stats dict)."""
+        out = np.zeros(self.n, dtype=np.uint32)
+        st = _lib.IngestStats()
+        check(lib().aix_count23_fixed_file(self._h, os.fsencode(path), fmt, canon_mode, _np_ptr(out), C.byref(st)), f"aix_count23_fixed_file({path})")
+        return out, st.as_dict()
+
+    def positions_fill(self, reads):
+        """A1 + A2: (indices uint64[n+1], positions uint64[sum tf]) = the .indices.bin / .index.bin images.
+        `reads`: bytes or any buffer (e.g. a numpy memmap of the reads file: nothing is copied on the host)."""
         a = np.frombuffer(reads, dtype=np.uint8)
         indices = np.empty(self.n + 1, dtype=np.uint64)
         total = C.c_uint64()

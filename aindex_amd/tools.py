@@ -22,14 +22,19 @@ from ._lib import check, lib, vp
 from .engine import Index
 
 
+def _mapped(path):
+    """The file as a read-only memory map (the library stages it through pinned memory part by part; no host copy is made here)."""
+    import os
+    return np.memmap(path, dtype=np.uint8, mode="r") if os.path.getsize(path) else np.zeros(0, dtype=np.uint8)
+
+
 def count_kmers13(argv) -> int:
     """count_kmers13.cpp:546-566: writes 4^13 u64 counts in mphf order."""
     if len(argv) < 3:
         print("Usage: count_kmers13 <input_file> <hash_file> <output_tf_file> [num_threads]", file=sys.stderr)
         return 1
-    buf = open(argv[0], "rb").read()
-    with Index.open_13(argv[1], None) as ix:
-        ix.count13(buf, _lib.FMT_AUTO).tofile(argv[2])
+    with Index.open_13(argv[1], None) as ix:                           # the input is streamed by the library: file -> pinned parts -> HBM -> table -> file
+        ix.count13_file(argv[0], argv[2], _lib.FMT_AUTO, want_array=False)
     return 0
 
 
@@ -48,7 +53,7 @@ def kmer_counter(argv) -> int:
         elif argv[i] == "--canon" and i + 1 < len(argv):
             canon = {"refx86": 1, "true": 2, "none": 0}[argv[i + 1]]; i += 1
         i += 1
-    keys, counts = counting.count_distinct(open(argv[0], "rb").read(), k, canon, min_count, _lib.FMT_FASTA)
+    keys, counts, _ = counting.count_distinct_file(argv[0], k, canon, min_count, _lib.FMT_FASTA)      # streamed, never a whole-file bytes object
     order = np.argsort(-counts.astype(np.int64), kind="stable")       # count descending (ties: key ascending)
     ks = np.ascontiguousarray(keys[order], dtype=np.uint64)
     cs = np.ascontiguousarray(counts[order], dtype=np.uint64)
@@ -86,7 +91,7 @@ def compute_index(argv) -> int:
         return 1
     check(st, "aix_dat_load")
     n = nn.value
-    pf = np.frombuffer(open(argv[1], "rb").read(), dtype=np.uint8)
+    pf = _mapped(argv[1])
     checker, tf = np.empty(n, dtype=np.uint64), np.empty(n, dtype=np.uint32)
     try:
         st = lib().aix_index_scatter(pf.ctypes.data_as(vp), pf.shape[0], kp, tp if not mock else None, n, 0, checker.ctypes.data_as(vp), tf.ctypes.data_as(vp))
@@ -141,7 +146,7 @@ def compute_aindex(argv) -> int:
     index_bin = argv[9] if len(argv) > 9 else prefix + ".index.bin"
     indices_bin = argv[10] if len(argv) > 10 else prefix + ".indices.bin"
     with Index.open_23(pf, tf_file, kmers_bin) as ix:
-        indices, pos = ix.positions_fill(open(reads_file, "rb").read())
+        indices, pos = ix.positions_fill(_mapped(reads_file))
     pos.tofile(index_bin)
     indices.tofile(indices_bin)
     return 0
@@ -159,7 +164,7 @@ def compute_aindex13(argv) -> int:
     index_bin = argv[6] if len(argv) > 6 else prefix + ".index.bin"
     indices_bin = argv[7] if len(argv) > 7 else prefix + ".indices.bin"
     with Index.open_13(pf, tf_file) as ix:
-        indices, pos = ix.positions_fill(open(reads_file, "rb").read())
+        indices, pos = ix.positions_fill(_mapped(reads_file))
     pos.tofile(index_bin)
     indices.tofile(indices_bin)
     return 0
@@ -170,6 +175,9 @@ COMMANDS = {"compute_aindex13": compute_aindex13, "count_kmers13": count_kmers13
 
 
 def main(argv=None) -> int:
+    import os
+    if "torch" not in sys.modules:
+        os.environ.setdefault("AIX_NO_TORCH", "1")                     # a tool run is file -> GPU -> file through the C ABI: no tensors, no torch import
     argv = list(sys.argv[1:] if argv is None else argv)
     if not argv or argv[0] not in COMMANDS:
         print(__doc__, file=sys.stderr)

@@ -218,6 +218,33 @@ int aix_count13_dev(aix_index_t* h, const char* d_plain, uint64_t len, uint64_t*
 int aix_count23_fixed(aix_index_t* h, const char* buf, uint64_t len, int format, int canon_mode, uint32_t* tf_out);
 int aix_count23_fixed_dev(aix_index_t* h, const char* d_plain, uint64_t len, int canon_mode,
                           uint32_t* d_tf_out /* accumulated into, caller zeroes */, void* stream);
+/* Streaming ingestion: the counters fed from a FILE, as the reference's tools are (count_kmers13.cpp:166-183,211-272,277-350: a reader
+ * thread pushes sequences while the workers count). The file is read part by part (AIX_INGEST_PART_MB, default 256) by several host
+ * threads into pinned staging, crosses the link on a copy stream while the previous part is normalised (FASTA / FASTQ readers as above,
+ * their state handed from part to part, so parts are cut at any byte) and counted; HBM use is O(part), the host never holds the file.
+ * Results are identical to the buffer forms. The host-buffer forms above (aix_count13, aix_count23_fixed, aix_count_distinct) run the same
+ * pipeline from caller memory.
+ * aix_count13_file: tf (u64[4^13], mphf order) is written to out_path (the file `count_kmers13 <in> <pf> <out>` writes,
+ *   count_kmers13.cpp:358-388) and / or copied to tf_out (either may be NULL, not both).
+ * stats (nullable) reports what the call did. */
+typedef struct {
+    uint64_t bytes_in;         /* bytes read from the file / buffer                                        */
+    uint64_t plain_bytes;      /* bytes of PLAIN form that were counted                                    */
+    uint64_t parts;            /* parts the input was cut into                                             */
+    uint64_t part_bytes;       /* size of a part                                                           */
+    uint64_t pieces;           /* K1: pieces whose distinct sets were merged                               */
+    uint64_t pinned_bytes;     /* pinned host staging held by the call                                     */
+    uint64_t device_bytes;     /* HBM held by the call: part staging + PLAIN part / piece + result (NOT the index, NOT the workspace)   */
+    uint64_t workspace_bytes;  /* the handle's counting workspace after the call (grow-only, sized by the largest part it has seen)      */
+    double seconds_total;      /* wall clock of the call                                                   */
+    double seconds_read;       /* file / page cache -> pinned staging (sum over parts, overlapped)         */
+    double seconds_wait;       /* the consumer waited for a part to arrive                                 */
+    double seconds_compute;    /* normalise + count as seen by the host (includes the waits inside)        */
+    double seconds_output;     /* result download + file write                                             */
+} aix_ingest_stats_t;
+int aix_count13_file(aix_index_t* h, const char* path, int format, const char* out_path /* nullable */, uint64_t* tf_out /* nullable */,
+                     aix_ingest_stats_t* stats);
+int aix_count23_fixed_file(aix_index_t* h, const char* path, int format, int canon_mode, uint32_t* tf_out /* u32[n] */, aix_ingest_stats_t* stats);
 /* K1 front end: replaces OptimizedKmerCounter's window loop (count_kmers.cpp:93-136,297-308) on a
  * PLAIN buffer in HBM: d_codes[p] = canonical 2-bit code of the k-window starting at byte p
  * (chars valid per count_kmers.cpp:71-88: ACGTU any case; canon_mode as above), or ~0 when the
@@ -278,18 +305,27 @@ int aix_positions_fill_shard_dev(aix_index_t* h, const char* d_reads, uint64_t l
  * (canonical k-mer code, count) with count >= min_count, sorted by code ascending (the reference sorts by count with
  * unspecified tie order; parity is on the set). *keys_out / *counts_out are malloc'd (aix_free). format as for the
  * counters (FASTA records follow count_kmers.cpp:250-295). 1 <= k <= 31; any length (buffers of more
- * than 2^31 windows are counted piece by piece and the distinct sets merged; counts are 64-bit). */
+ * than 2^31 windows are counted piece by piece and the sorted distinct sets MERGED, never re-sorted — count_kmers.cpp:334-341 merges its
+ * per-thread maps once; counts and sizes are 64-bit). */
 int aix_count_distinct(const char* buf, uint64_t len, int format, int k, int canon_mode, uint64_t min_count, int device,
                        uint64_t** keys_out, uint64_t** counts_out, uint64_t* n_out);
+/* the same from a file, streamed (see aix_count13_file): pieces of 2^31 windows are counted as the parts arrive, their sorted sets merged */
+int aix_count_distinct_file(const char* path, int format, int k, int canon_mode, uint64_t min_count, int device, uint64_t** keys_out,
+                            uint64_t** counts_out, uint64_t* n_out, aix_ingest_stats_t* stats);
 /* device-resident twin: d_plain is a PLAIN buffer in HBM; the (key, count) arrays stay in HBM inside *out until the caller
  * has sized its own arrays (aix_distinct_size) and copied them (aix_distinct_copy_dev: u64 keys ascending, u64 counts). */
 typedef struct aix_distinct aix_distinct_t;
 int aix_count_distinct_dev(const char* d_plain, uint64_t len, int k, int canon_mode, uint64_t min_count, int device, void* stream,
                            aix_distinct_t** out);
 /* K1 across GPUs: (key, count) pairs with repeated keys (what a rank holds after the all-to-all by key owner) -> the same kind
- * of result object: keys ascending, counts of equal keys summed, counts >= min_count. n < 2^32. */
+ * of result object: keys ascending, counts of equal keys summed, counts >= min_count. Pairs in any order (sort + reduce-by-key). */
 int aix_merge_counts_dev(const uint64_t* d_keys, const uint64_t* d_counts, uint64_t n, uint64_t min_count, int device, void* stream,
                          aix_distinct_t** out);
+/* the same when the caller can name its runs: run r = entries [run_offsets[r], run_offsets[r + 1]) (HOST array of nruns + 1 offsets), each run
+ * sorted by key and free of repeats — after the exchange a rank holds one such run per peer, as the reference's merge holds one map per
+ * thread (count_kmers.cpp:334-341). A tree of two-way merges with summation; nothing is sorted, any size. */
+int aix_merge_runs_dev(const uint64_t* d_keys, const uint64_t* d_counts, const uint64_t* run_offsets, uint32_t nruns, uint64_t min_count, int device,
+                       void* stream, aix_distinct_t** out);
 int aix_distinct_size(const aix_distinct_t* r, uint64_t* n_out);
 int aix_distinct_copy_dev(const aix_distinct_t* r, uint64_t* d_keys, uint64_t* d_counts, void* stream);
 void aix_distinct_free(aix_distinct_t* r);

@@ -251,6 +251,16 @@ void aixo_tf23_batch(const aixo_index23* ix, const char* kmers, uint64_t N, uint
 void aixo_hash23_batch(const aixo_index23* ix, const char* kmers, uint64_t N, uint64_t* out) {
     for (uint64_t i = 0; i < N; ++i) out[i] = aixo_hash23(ix, kmers + 23 * i, 23); /* :629-636 */
 }
+/* the remaining single-k-mer queries over a batch (plain loops over the functions above; the full-size config-3 test asks 10^6 of each) */
+void aixo_info23_batch(const aixo_index23* ix, const char* kmers, uint64_t N, uint64_t* kid, uint8_t* strand, uint64_t* total, uint32_t* fwd, uint32_t* rc) {
+    for (uint64_t i = 0; i < N; ++i) {
+        const char* s = kmers + 23 * i;
+        kid[i] = aixo_kid23(ix, s, 23);
+        strand[i] = (uint8_t)aixo_strand23(ix, s, 23);
+        total[i] = aixo_total23(ix, s, 23);
+        aixo_both23(ix, s, 23, fwd + i, rc + i);
+    }
+}
 
 typedef struct { const void* ix; const char* kmers; uint64_t lo, hi; uint32_t* out; int k; } mt_job;
 static void* tf23_worker(void* p) {

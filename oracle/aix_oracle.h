@@ -71,6 +71,7 @@ uint64_t aixo_hash23(const aixo_index23* ix, const char* s, uint64_t len);    /*
 void aixo_tf23_batch(const aixo_index23* ix, const char* kmers, uint64_t N, uint32_t* out);
 void aixo_tf23_batch_mt(const aixo_index23* ix, const char* kmers, uint64_t N, uint32_t* out, int nthreads);
 void aixo_hash23_batch(const aixo_index23* ix, const char* kmers, uint64_t N, uint64_t* out);
+void aixo_info23_batch(const aixo_index23* ix, const char* kmers, uint64_t N, uint64_t* kid, uint8_t* strand, uint64_t* total, uint32_t* fwd, uint32_t* rc);
 
 /* ---- Q3/Q4 13-mer queries, src/python_wrapper.cpp:482-503,522-608,938-980 ---- */
 typedef struct {

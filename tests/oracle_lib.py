@@ -140,6 +140,16 @@ class OracleIndex23:
         lib().aixo_hash23_batch(C.byref(self.s), _p(kmers, C.c_char_p), C.c_uint64(n), _p(out, u64p))
         return out
 
+    def info_batch(self, kmers: np.ndarray):
+        """(kid u64, strand u8, total u64, fwd u32, rc u32) of every 23-mer of a contiguous N*23 byte array."""
+        kmers = np.ascontiguousarray(kmers, dtype=np.uint8).reshape(-1)
+        n = kmers.shape[0] // 23
+        kid, strand, total = np.empty(n, np.uint64), np.empty(n, np.uint8), np.empty(n, np.uint64)
+        fwd, rc = np.empty(n, np.uint32), np.empty(n, np.uint32)
+        lib().aixo_info23_batch(C.byref(self.s), _p(kmers, C.c_char_p), C.c_uint64(n), _p(kid, u64p), _p(strand, C.POINTER(C.c_uint8)), _p(total, u64p),
+                                _p(fwd, u32p), _p(rc, u32p))
+        return kid, strand, total, fwd, rc
+
     def coverage(self, seq: bytes, cutoff: int = 0) -> np.ndarray:
         out = np.zeros(max(0, len(seq) - 22), dtype=np.uint32)
         lib().aixo_coverage23(C.byref(self.s), seq, C.c_uint64(len(seq)), C.c_uint32(cutoff), _p(out, u32p))

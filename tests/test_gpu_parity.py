@@ -987,7 +987,7 @@ def config3_index():
     keys, counts = counting.count_distinct_t(g, 23, _lib.CANON_TRUE_RC)
     pf = builder.build_pf_codes_t(keys, 23)
     ix = Index.build_23_codes_t(pf, keys, counts.to(torch.int32))
-    yield {"ix": ix, "g": g, "keys": keys, "counts": counts}
+    yield {"ix": ix, "g": g, "keys": keys, "counts": counts, "pf": pf}
     ix.close()
 
 
@@ -1022,6 +1022,73 @@ def test_config4_share_of_25M_reads_properties(config3_index):
     finally:
         del os.environ["AIX_COUNT23_ATOMICS"]
     assert torch.equal(tf_a, tf)
+
+
+def test_config3_full_size_index_against_the_oracle(config3_index, tmp_path):
+    """The 5e7-key index of configs[2] itself against the oracle (until now it was only checked through properties and
+    HIP-vs-HIP): (a) every stored key, forward and reverse-complemented, through the codes entry point == its count; (b) 2e7 Q_mix + 2e7
+    Q_rand (the bench's generators) with N / lower-case sprinkled in, against the oracle's get_tf_values on all host cores; (c) the same
+    with the verification table off and with the absence filter off; (d) total / both / kid / strand / hash on 1e6 of them."""
+    import torch
+    from aindex_amd import engine
+    ix, g, keys, counts = config3_index["ix"], config3_index["g"], config3_index["keys"], config3_index["counts"]
+    n = keys.numel()
+    assert 49_000_000 < n < 51_000_000 and ix.canonical_only
+    # (a) all keys, both strands
+    M = (1 << 46) - 1
+    x = (~keys) & M
+
+    def swap(v, m, s):
+        return ((v >> s) & m) | ((v & m) << s)
+    x = swap(x, 0x3333333333333333, 2)
+    x = swap(x, 0x0F0F0F0F0F0F0F0F, 4)
+    x = swap(x, 0x00FF00FF00FF00FF, 8)
+    x = swap(x, 0x0000FFFF0000FFFF, 16)
+    x = swap(x, 0x00000000FFFFFFFF, 32)
+    rc = (x >> 18) & M
+    want32 = counts.to(torch.int32)
+    assert torch.equal(ix.tf_codes_t(keys), want32)
+    assert torch.equal(ix.tf_codes_t(rc), want32)
+    assert bool((rc >= keys).all())                                         # true-canonical key set
+    del x, rc
+    # the oracle on the same index files (written from the handle: what load_hash would read, hash.cpp:367-450)
+    prefix = str(tmp_path / "c3")
+    open(prefix + ".pf", "wb").write(config3_index["pf"])                    # the image the handle was built from (GPU builder)
+    ix.tf_array().tofile(prefix + ".tf.bin")
+    ix.checker_array().tofile(prefix + ".kmers.bin")
+    orc = O.OracleIndex23.from_prefix(prefix)
+    assert orc.n == n
+    # (b) queries
+    nq = 20_000_000
+    q = torch.cat([engine.synth_mix23_t(8, g, nq), engine.synth_kmers_t(7, nq, 23)]).cpu().numpy().reshape(-1, 23).copy()
+    idx = np.arange(0, q.shape[0], 97)
+    q[idx, (idx * 7) % 23] = ord("N")
+    idx = np.arange(5, q.shape[0], 131)
+    q[idx] |= 0x20
+    flatq = q.reshape(-1)
+    want = orc.tf_batch(flatq, threads=max(1, min(64, os.cpu_count() or 1)))
+    assert int((want != 0).sum()) > nq // 3
+    assert np.array_equal(ix.tf_ascii(flatq), want)
+    # (c) table off / filter off
+    try:
+        ix.set_bucket_table(False)
+        assert np.array_equal(ix.tf_ascii(flatq), want)
+        ix.set_bucket_table(True)
+        ix.set_absence_filter(False)
+        assert np.array_equal(ix.tf_ascii(flatq), want)
+    finally:
+        ix.set_bucket_table(True)
+        ix.set_absence_filter(True)
+    # (d) the other query kinds on 1e6 (every 40th query: both generators, sprinkles included)
+    sub = np.ascontiguousarray(q[::40]).reshape(-1)
+    okid, ostrand, ototal, ofwd, orc_ = orc.info_batch(sub)
+    kid, strand = ix.kid_strand_ascii(sub)
+    assert np.array_equal(kid, okid) and np.array_equal(strand, ostrand)
+    assert np.array_equal(ix.total_ascii(sub), ototal)
+    f, r = ix.both_ascii(sub)
+    assert np.array_equal(f, ofwd.astype(np.uint64)) and np.array_equal(r, orc_.astype(np.uint64))
+    assert np.array_equal(ix.hash_ascii(sub), orc.hash_batch(sub))
+    assert np.array_equal(ix.tf_ascii(sub), want[::40])
 
 
 def test_config5_coverage_100k_sequences_properties(config3_index, ix13):
