@@ -107,6 +107,165 @@ def timed_steps(step_fn, steps, warmup, device, collective=True):
     return wall, float(np.mean(kern_ms)), kern_ms
 
 
+def scratch_dir(need_bytes, cache):
+    """Where the end-to-end workloads put their input files: /dev/shm (page-cache speed: the measurement is the pipeline, not a disk)
+    when it has the room, else the bench cache directory."""
+    import shutil
+    for d in ("/dev/shm", cache):
+        try:
+            os.makedirs(d, exist_ok=True)
+            if shutil.disk_usage(d).free > need_bytes + (2 << 30):
+                return d
+        except OSError:
+            pass
+    return cache
+
+
+def write_reads_file(path, genome_t, seed, n_reads, fmt, dev, rc_half=False, block=4_000_000):
+    """n_reads synthetic 150 bp reads (the seed's stream, reads [0, n_reads)) as a PLAIN (one read per line) or FASTQ file; generated
+    in HBM block by block, never held whole on the host. Returns the file size."""
+    from aindex_amd import engine
+    size = 0
+    with open(path, "wb") as f:
+        for first in range(0, n_reads, block):
+            m = min(block, n_reads - first)
+            r = engine.synth_reads_t(seed, genome_t, m, 150, rc_half=rc_half, n_rate_ppm=1000, first_read=first).cpu().numpy()
+            if fmt == "fastq":
+                fq = np.empty((m, 4 + 151 + 2 + 151), dtype=np.uint8)
+                fq[:, :4] = np.frombuffer(b"@r0\n", dtype=np.uint8)
+                fq[:, 4:155] = r.reshape(m, 151)
+                fq[:, 155:157] = np.frombuffer(b"+\n", dtype=np.uint8)
+                fq[:, 157:307] = ord("I")
+                fq[:, 307] = ord("\n")
+                r = fq.reshape(-1)
+            r.tofile(f)
+            size += r.shape[0]
+    return size
+
+
+def measure_e2e13(dev, cache, gigabytes, pf13, with_reference=True):
+    """END TO END, the tool path: a reads FILE -> bin/count_kmers13 <file> <pf> <out> -> the 512 MiB tf file, wall clock of the whole
+    process (python start, HIP init, index load, streamed ingestion, output file). Beside it: the same call inside this process
+    (aix_count13_file: no process start, no index load), a FASTQ file of a quarter of the size, the reference binary on a bounded sample."""
+    import subprocess
+    import torch
+    from aindex_amd import engine
+    from aindex_amd.engine import Index
+    n_reads = int(gigabytes * 1e9) // 151
+    d = scratch_dir(int(gigabytes * 1.3e9) + (1 << 30), cache)
+    g = engine.synth_genome_t(13, 4_000_000, dev)
+    p_plain, p_fq, p_out, p_out2 = (os.path.join(d, f"aix_e2e13_{os.getpid()}{x}") for x in (".txt", ".fq", ".tf.bin", ".tf2.bin"))
+    res = {"metric": "end_to_end_count_kmers13", "scratch": d, "reads": n_reads}
+    try:
+        t0 = time.perf_counter()
+        size = write_reads_file(p_plain, g, 14, n_reads, "plain", dev)
+        res["file_bytes"] = size
+        res["file_written_s"] = time.perf_counter() - t0
+        ix = Index.open_13(pf13, None, dev)
+        # the answer, from the device-resident path, block by block (tf accumulates in the comparison only)
+        want = torch.zeros(4 ** 13, dtype=torch.int64, device=f"cuda:{dev}")
+        for first in range(0, n_reads, 8_000_000):
+            m = min(8_000_000, n_reads - first)
+            want += ix.count13_t(engine.synth_reads_t(14, g, m, 150, n_rate_ppm=1000, first_read=first))
+        want = want.cpu().numpy().view(np.uint64)
+        # (1) in process: the streamed call alone
+        best = None
+        for _ in range(2):
+            _, st = ix.count13_file(p_plain, p_out2, want_array=False)
+            if best is None or st["seconds_total"] < best["seconds_total"]:
+                best = st
+        assert np.array_equal(np.fromfile(p_out2, dtype=np.uint64), want), "streamed count differs from the device-resident count"
+        res["in_process"] = {"seconds": best["seconds_total"], "GBps": size / best["seconds_total"] / 1e9, "reads_per_s": n_reads / best["seconds_total"],
+                             "stats": best, "note": "aix_count13_file: file -> pinned parts -> HBM -> table -> 512 MiB output file; index already open"}
+        no_out = ix.count13_file(p_plain, None, want_array=True)[1]
+        res["in_process_result_to_memory"] = {"seconds": no_out["seconds_total"], "GBps": size / no_out["seconds_total"] / 1e9}
+        ix.close()
+        torch.cuda.empty_cache()
+        # (2) the tool, as a process
+        exe = os.path.join(ROOT, "bin", "count_kmers13")
+        t0 = time.perf_counter()
+        r = subprocess.run([sys.executable, exe, p_plain, pf13, p_out, "16"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=900)
+        dt = time.perf_counter() - t0
+        if r.returncode != 0:
+            raise RuntimeError("bin/count_kmers13 failed: " + r.stderr.decode()[-300:])
+        assert np.array_equal(np.fromfile(p_out, dtype=np.uint64), want), "tool output differs from the device-resident count"
+        res.update({"value": n_reads / dt, "unit": "reads/s", "seconds": dt, "GBps": size / dt / 1e9,
+                    "note": "wall clock of `bin/count_kmers13 <file> <pf> <out>` as a child process, output file byte-equal to the device-resident count"})
+        # (3) FASTQ, a quarter of the reads: the normaliser sits in the pipeline
+        nq = max(1, n_reads // 4)
+        sq = write_reads_file(p_fq, g, 14, nq, "fastq", dev)
+        ix = Index.open_13(pf13, None, dev)
+        wq = torch.zeros(4 ** 13, dtype=torch.int64, device=f"cuda:{dev}")
+        for first in range(0, nq, 8_000_000):
+            m = min(8_000_000, nq - first)
+            wq += ix.count13_t(engine.synth_reads_t(14, g, m, 150, n_rate_ppm=1000, first_read=first))
+        gq, stq = ix.count13_file(p_fq, None)
+        assert np.array_equal(gq, wq.cpu().numpy().view(np.uint64)), "streamed FASTQ count differs from the device-resident count"
+        res["fastq_in_process"] = {"file_bytes": sq, "reads": nq, "seconds": stq["seconds_total"], "GBps": sq / stq["seconds_total"] / 1e9,
+                                   "reads_per_s": nq / stq["seconds_total"], "stats": stq}
+        ix.close()
+        # (4) the reference's own binary on the head of the same file
+        ref = os.path.join(ROOT, "oracle", "_ref", "count_kmers13")
+        if with_reference and os.path.exists(ref):
+            ns = min(n_reads, 200_000)
+            p_s = p_plain + ".sample"
+            with open(p_plain, "rb") as f, open(p_s, "wb") as o:
+                o.write(f.read(ns * 151))
+            try:
+                t0 = time.perf_counter()
+                subprocess.run([ref, p_s, pf13, p_out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900, check=True)
+                dtr = time.perf_counter() - t0
+                res["cpu_baseline"] = {"value": ns / dtr, "unit": "reads/s", "cores": os.cpu_count() or 1, "kind": "reference",
+                                       "sample": f"first {ns} reads of the same file through oracle/_ref/count_kmers13 (wall clock of the process, its default threads)"}
+            except Exception as e:
+                log(f"e2e13: reference binary not usable ({type(e).__name__}: {e})")
+            finally:
+                try:
+                    os.remove(p_s)
+                except OSError:
+                    pass
+    finally:
+        for f in (p_plain, p_fq, p_out, p_out2):
+            try:
+                os.remove(f)
+            except OSError:
+                pass
+    return res
+
+
+def measure_e2e23(ix, g, dev, cache, gigabytes):
+    """END TO END for the config-4 histogram: a reads FILE (seed 41, 50 % reverse strand, 0.1 % N) -> aix_count23_fixed_file -> tf[n] in host
+    memory, wall clock of the call; the result equals the device-resident count of the same reads."""
+    import torch
+    from aindex_amd import engine, _lib
+    n_reads = int(gigabytes * 1e9) // 151
+    d = scratch_dir(int(gigabytes * 1.05e9) + (1 << 30), cache)
+    path = os.path.join(d, f"aix_e2e23_{os.getpid()}.txt")
+    res = {"metric": "end_to_end_count23_fixed_file", "scratch": d, "reads": n_reads, "index_keys": ix.n}
+    try:
+        size = write_reads_file(path, g, 41, n_reads, "plain", dev, rc_half=True)
+        want = torch.zeros(ix.n, dtype=torch.int32, device=f"cuda:{dev}")
+        for first in range(0, n_reads, 8_000_000):
+            m = min(8_000_000, n_reads - first)
+            ix.count23_fixed_t(engine.synth_reads_t(41, g, m, 150, rc_half=True, n_rate_ppm=1000, first_read=first), _lib.CANON_TRUE_RC, want)
+        want = want.cpu().numpy().view(np.uint32)
+        best = None
+        for _ in range(2):
+            got, st = ix.count23_fixed_file(path, _lib.FMT_PLAIN, _lib.CANON_TRUE_RC)
+            assert np.array_equal(got, want), "streamed count23 differs from the device-resident count"
+            if best is None or st["seconds_total"] < best["seconds_total"]:
+                best = st
+        res.update({"file_bytes": size, "value": n_reads / best["seconds_total"], "unit": "reads/s", "seconds": best["seconds_total"],
+                    "GBps": size / best["seconds_total"] / 1e9, "stats": best,
+                    "note": "aix_count23_fixed_file: file -> pinned parts -> HBM -> probe + histogram -> tf[n] in host memory"})
+    finally:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+    return res
+
+
 def cpu_baseline_lookup23(ix, pf, q_sample_np, gpu_sample, tmpdir):
     """CPU path timed on this host on a bounded sample of the same queries against the same index:
     the compiled reference itself (oracle/_ref/aindex_cpp, single-threaded batch get_tf_values through
@@ -592,7 +751,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="auto", choices=["auto", "lookup23", "lookup13", "count13", "count23", "gather", "coverage23", "coverage13", "positions23", "normalize", "distinct23", "selftest"],
+    ap.add_argument("--workload", default="auto", choices=["auto", "lookup23", "lookup13", "count13", "count23", "gather", "coverage23", "coverage13", "positions23", "normalize", "distinct23", "e2e13", "e2e23", "selftest"],
                     help="auto: N = 1 -> lookup23 (BASELINE configs[2], the headline), N > 1 -> count23 --scaling strong (configs[3])")
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"], help="count23: strong = --total-reads split over the ranks (config 4); weak = --reads per rank")
     ap.add_argument("--total-reads", type=int, default=200_000_000, help="reads of the strong-scaling counting workload (config 4: 200 M)")
@@ -610,6 +769,8 @@ def main():
                     help="positions23: tf of the index = occurrences in the reads (every found window is placed; the reference pipeline) or in the genome (tf = 1: first occurrences only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather-probe", action="store_true", help="skip the live random-read roofline measurement")
+    ap.add_argument("--e2e-gb", type=float, default=8.0, help="size of the reads file of the end-to-end (file in, file out) measurements")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end tool measurements of the default workload's secondary block")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary counting measurement of the default workload")
     ap.add_argument("--reads13", type=int, default=10_000_000, help="reads per rank and step of the secondary 13-mer counting measurement (configs[1])")
     ap.add_argument("--reads23", type=int, default=10_000_000, help="reads per rank and step of the secondary counting measurement (config 4 has 25 M per GPU at N = 8)")
@@ -720,7 +881,40 @@ def main():
                 del reads13, tf13, g13
             except Exception as e:  # pragma: no cover
                 sec["count13_dense"] = {"error": f"{type(e).__name__}: {e}"}
+            # the tool path end to end: reads FILE -> bin/count_kmers13 -> tf file, and the config-4 histogram from a file
+            if rank == 0 and world == 1 and not a.no_e2e:
+                try:
+                    from aindex_amd.builder import all_13mers_pf_path as pf13_path
+                    sec["e2e13"] = measure_e2e13(dev, cache, a.e2e_gb, pf13_path(), with_reference=not a.no_cpu_baseline)
+                except Exception as e:  # pragma: no cover
+                    sec["e2e13"] = {"error": f"{type(e).__name__}: {e}"}
+                try:
+                    sec["e2e23"] = measure_e2e23(ix, g, dev, cache, a.e2e_gb)
+                except Exception as e:  # pragma: no cover
+                    sec["e2e23"] = {"error": f"{type(e).__name__}: {e}"}
             out["secondary"] = sec
+
+    elif a.workload == "e2e13":
+        from aindex_amd.builder import all_13mers_pf_path as pf13_path
+        r = measure_e2e13(dev, cache, a.e2e_gb, pf13_path(), with_reference=not a.no_cpu_baseline)
+        cb = r.pop("cpu_baseline", None)
+        out.update({"metric": "reads_per_sec_count_kmers13_tool_end_to_end", "value": r["value"], "unit": "reads/s", "ms_per_step": r["seconds"] * 1e3, "steps": 1, "warmup": 0,
+                    "dtype": "u64", "config": {"workload": f"bin/count_kmers13 on a {r['file_bytes'] / 1e9:.2f} GB PLAIN reads file (150 bp, seed 14) in {r['scratch']}: "
+                                                           "process start + index load + streamed ingestion + 512 MiB output file", **{k: v for k, v in r.items() if k not in ("value", "unit")}},
+                    **({"cpu_baseline": cb} if cb else {}),
+                    "roofline": {"bound": "hbm", "achieved": r["in_process"]["GBps"], "peak": 64.0, "unit": "GB/s", "frac": r["in_process"]["GBps"] / 64.0, "traffic": None,
+                                 "kernel": "H2D copies of the parts (the link, not a kernel, bounds this path)",
+                                 "note": "peak = PCIe 5 x16 (64 GB/s raw; ~51 GB/s measured with pinned memory, profiles/r02/hostpath.json); achieved = file bytes / in-process call"}})
+
+    elif a.workload == "e2e23":
+        ix, g, keys, counts, pf = build_index23(a.genome, rank, world, dev, cache)
+        del keys, counts
+        r = measure_e2e23(ix, g, dev, cache, a.e2e_gb)
+        out.update({"metric": "reads_per_sec_count23_fixed_file_end_to_end", "value": r["value"], "unit": "reads/s", "ms_per_step": r["seconds"] * 1e3, "steps": 1, "warmup": 0,
+                    "dtype": "u64", "config": {"workload": f"aix_count23_fixed_file on a {r['file_bytes'] / 1e9:.2f} GB PLAIN reads file (150 bp, seed 41) in {r['scratch']}", **r},
+                    "roofline": {"bound": "hbm", "achieved": r["GBps"], "peak": 64.0, "unit": "GB/s", "frac": r["GBps"] / 64.0, "traffic": None,
+                                 "kernel": "H2D copies of the parts overlapped with k_probe23_slots + histogram",
+                                 "note": "peak = PCIe 5 x16 (64 GB/s raw); the resident kernel counts ~40 GB/s of reads, so link and kernel are of one size here"}})
 
     elif a.workload == "lookup13":
         from aindex_amd.engine import Index
