@@ -44,7 +44,7 @@ class Info(C.Structure):
 class IngestStats(C.Structure):
     _fields_ = [("bytes_in", C.c_uint64), ("plain_bytes", C.c_uint64), ("parts", C.c_uint64), ("part_bytes", C.c_uint64), ("pieces", C.c_uint64),
                 ("pinned_bytes", C.c_uint64), ("device_bytes", C.c_uint64), ("workspace_bytes", C.c_uint64), ("seconds_total", C.c_double), ("seconds_read", C.c_double),
-                ("seconds_wait", C.c_double), ("seconds_compute", C.c_double), ("seconds_output", C.c_double)]
+                ("seconds_wait", C.c_double), ("seconds_h2d", C.c_double), ("seconds_compute", C.c_double), ("seconds_output", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -95,6 +95,7 @@ SIGNATURES = {
     "aix_count13_dev": (i32, [vp, vp, u64, vp, vp]),
     "aix_count23_fixed": (i32, [vp, vp, u64, i32, i32, vp]),
     "aix_count23_fixed_dev": (i32, [vp, vp, u64, i32, vp, vp]),
+    "aix_ingest_warm": (i32, [i32]),
     "aix_count13_file": (i32, [vp, C.c_char_p, i32, C.c_char_p, vp, C.POINTER(IngestStats)]),
     "aix_count23_fixed_file": (i32, [vp, C.c_char_p, i32, i32, vp, C.POINTER(IngestStats)]),
     "aix_count_distinct_file": (i32, [C.c_char_p, i32, i32, i32, u64, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), C.POINTER(IngestStats)]),

@@ -58,7 +58,7 @@ extern "C" int aix_device_count(int* count) {
     return AIX_OK;
 }
 
-extern "C" void aix_scratch_trim(void) { pool_trim(); }
+extern "C" void aix_scratch_trim(void) { pool_trim(); pinned_trim(); }
 
 extern "C" uint64_t aix_selftest_mod(uint64_t h, uint64_t d) { return fastmod(h, make_fastmod(d)); }
 extern "C" uint64_t aix_selftest_revcomp(uint64_t code, int k) { return revcomp(code, k); }

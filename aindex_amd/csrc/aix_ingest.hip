@@ -104,9 +104,66 @@ HostWorkers& host_workers() {
     return pool;
 }
 
+// ---------------------------------------------------------------------------------------------
+// pinned staging blocks are kept between calls (pinning 64 MiB costs ~10 ms; a call needs three to five of them): a process that counts
+// file after file pays once. AIX_PINNED_CACHE_MB (default 1024) bounds what is kept; aix_scratch_trim() frees it.
+// ---------------------------------------------------------------------------------------------
+struct PinnedPool {
+    std::mutex mu;
+    std::vector<std::pair<void*, uint64_t>> free_blocks;
+    uint64_t cached = 0;
+    static uint64_t limit() {
+        static const uint64_t lim = [] { const char* e = getenv("AIX_PINNED_CACHE_MB"); return (uint64_t)(e ? atol(e) : 1024) << 20; }();
+        return lim;
+    }
+    void* get(uint64_t bytes) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t i = 0; i < free_blocks.size(); ++i)
+                if (free_blocks[i].second == bytes) {
+                    void* p = free_blocks[i].first;
+                    free_blocks.erase(free_blocks.begin() + (long)i);
+                    cached -= bytes;
+                    return p;
+                }
+        }
+        void* p = nullptr;
+        if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        return p;
+    }
+    void put(void* p, uint64_t bytes) {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (cached + bytes <= limit()) { free_blocks.emplace_back(p, bytes); cached += bytes; return; }
+        }
+        (void)hipHostFree(p);
+    }
+    void trim() {
+        std::vector<std::pair<void*, uint64_t>> b;
+        { std::lock_guard<std::mutex> lk(mu); b.swap(free_blocks); cached = 0; }
+        for (auto& x : b) (void)hipHostFree(x.first);
+    }
+};
+PinnedPool& pinned_pool() { static PinnedPool* p = new PinnedPool(); return *p; }     // never destroyed: the HIP runtime may be gone at exit
+
 }  // namespace
 
 namespace aix {
+
+void pinned_trim() { pinned_pool().trim(); }
+
+// pin the staging blocks of one streaming call in the background (a tool does this before it opens its index: by the time the first
+// part is read the blocks are there)
+void pinned_warm(int device) {
+    const uint64_t part = ingest_part_bytes();
+    std::thread([part, device] {
+        if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return; }
+        void* b[5];
+        for (int i = 0; i < 5; ++i) b[i] = pinned_pool().get(i < 3 ? part : (32ull << 20));
+        for (int i = 0; i < 5; ++i) pinned_pool().put(b[i], i < 3 ? part : (32ull << 20));
+    }).detach();
+}
 
 // ---------------------------------------------------------------------------------------------
 // ByteSource
@@ -173,14 +230,16 @@ Ingest::Ingest(const ByteSource& s, uint64_t part, int dev) : src(s), part_bytes
 
 int Ingest::start(uint8_t* direct_dst) {
     direct = direct_dst;
+    // (copies of consecutive parts on two alternating streams were measured: 41.9 / 38.9 / 32.7 GB/s with 32 / 64 / 128 MiB parts against
+    // 43.8 GB/s with one stream and 64 MiB parts on the same box — one stream it is)
     if (hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return AIX_ERR_HIP; }
     for (int b = 0; b < NB; ++b) {
-        if (hipEventCreateWithFlags(&h2d_ev[b], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&used_ev[b], hipEventDisableTiming) != hipSuccess) {
+        if (hipEventCreate(&h2d_ev[b]) != hipSuccess || hipEventCreate(&h2d_t0[b]) != hipSuccess || hipEventCreateWithFlags(&used_ev[b], hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();
             return AIX_ERR_HIP;
         }
         if (!direct) {
-            if (hipMalloc((void**)&dbuf[b], HDR + part_bytes + 64) != hipSuccess) { (void)hipGetLastError(); return AIX_ERR_NOMEM; }
+            if (pool_alloc((void**)&dbuf[b], HDR + part_bytes + 64) != hipSuccess) { (void)hipGetLastError(); return AIX_ERR_NOMEM; }
             device_bytes += HDR + part_bytes + 64;
         }
     }
@@ -206,9 +265,14 @@ void Ingest::produce() {
         if (src.mem && src.mem_pinned) {
             wire = src.mem + off;                               // the caller pinned its buffer: it goes over the wire as it is
         } else {
-            if (c >= (uint64_t)NB && hipEventSynchronize(h2d_ev[b]) != hipSuccess) { fail(AIX_ERR_HIP); return; }   // staging buffer b is off the wire
+            if (c >= (uint64_t)NB) {                            // staging buffer b is off the wire
+                if (hipEventSynchronize(h2d_ev[b]) != hipSuccess) { fail(AIX_ERR_HIP); return; }
+                float ms = 0;
+                if (hipEventElapsedTime(&ms, h2d_t0[b], h2d_ev[b]) == hipSuccess) seconds_h2d += ms * 1e-3; else (void)hipGetLastError();
+            }
             if (!pin[b]) {                                      // allocated when first needed: the later ones while the first parts are already moving
-                if (hipHostMalloc(&pin[b], part_bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); fail(AIX_ERR_NOMEM); return; }
+                pin[b] = pinned_pool().get(part_bytes);
+                if (!pin[b]) { fail(AIX_ERR_NOMEM); return; }
                 pinned_bytes += part_bytes;
             }
             const double t0 = now_s();
@@ -229,7 +293,8 @@ void Ingest::produce() {
             std::lock_guard<std::mutex> lk(mu);
             if (abort_flag) return;
         }
-        if (hipMemcpyAsync(dst, wire, m, hipMemcpyHostToDevice, copy_stream) != hipSuccess || hipEventRecord(h2d_ev[b], copy_stream) != hipSuccess) {
+        if (hipEventRecord(h2d_t0[b], copy_stream) != hipSuccess || hipMemcpyAsync(dst, wire, m, hipMemcpyHostToDevice, copy_stream) != hipSuccess ||
+            hipEventRecord(h2d_ev[b], copy_stream) != hipSuccess) {
             fail(AIX_ERR_HIP);
             return;
         }
@@ -290,15 +355,18 @@ Ingest::~Ingest() {
     }
     if (copy_stream) (void)hipStreamSynchronize(copy_stream);
     for (int b = 0; b < NB; ++b) {
-        if (pin[b]) (void)hipHostFree(pin[b]);
-        if (dbuf[b]) (void)hipFree(dbuf[b]);
+        if (pin[b]) pinned_pool().put(pin[b], part_bytes);
+        if (dbuf[b]) pool_free(dbuf[b]);
         if (h2d_ev[b]) (void)hipEventDestroy(h2d_ev[b]);
+        if (h2d_t0[b]) (void)hipEventDestroy(h2d_t0[b]);
         if (used_ev[b]) (void)hipEventDestroy(used_ev[b]);
     }
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
 }
 
 uint64_t ingest_part_bytes() {
+    // 256 MiB parts, three in flight: 47.5 GB/s for an 8 GB PLAIN file with warm staging blocks (64 MiB: 43.8, 12 reader threads; 8 threads:
+    // 37, 4: 22 — DESIGN.md 5). Pinning a block costs ~35 ms, so a process that will stream ONE file warms the pool first (aix_ingest_warm).
     uint64_t mb = 256;
     if (const char* e = getenv("AIX_INGEST_PART_MB")) { const long v = atol(e); if (v >= 1 && v <= 2047) mb = (uint64_t)v; }
     uint64_t bytes = mb << 20;
@@ -399,6 +467,7 @@ void PlainStream::fill_stats(aix_ingest_stats_t* st) const {
     st->device_bytes = in.device_bytes + plain_dev_bytes;
     st->seconds_read = in.seconds_read;
     st->seconds_wait = in.seconds_wait;
+    st->seconds_h2d = in.seconds_h2d;
 }
 
 }  // namespace aix
@@ -447,56 +516,94 @@ static int count23_source(aix_index_t* h, const ByteSource& src, int format, int
     return st;
 }
 
-// The result of a counting call. To a file: D2H in 64 MiB slices through two pinned buffers, slice i written (host threads, pwrite)
-// while slice i + 1 crosses the link. To caller memory: one copy (pinned destinations at link rate; pageable ones staged by the runtime).
-static int download(void* host_dst, const char* out_path, const void* d_src, uint64_t bytes, hipStream_t s, aix_ingest_stats_t* stats) {
+// The output file of a tool run is created and its pages allocated WHILE the input is being counted (tmpfs / page cache allocate and zero
+// 512 MiB at a few GB/s; done afterwards that is a third of the whole call): a background thread, joined before the result is written.
+struct OutputFile {
+    int fd = -1;
+    std::thread th;
+    int open_and_reserve(const char* path, uint64_t bytes) {
+        fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (fd < 0) return AIX_ERR_IO;
+        const int f = fd;
+        th = std::thread([f, bytes] { if (bytes && posix_fallocate(f, 0, (off_t)bytes) != 0) (void)ftruncate(f, (off_t)bytes); });
+        return AIX_OK;
+    }
+    void ready() { if (th.joinable()) th.join(); }
+    int close_file() {
+        ready();
+        int st = AIX_OK;
+        if (fd >= 0 && ::close(fd) != 0) st = AIX_ERR_IO;
+        fd = -1;
+        return st;
+    }
+    ~OutputFile() { ready(); if (fd >= 0) ::close(fd); }
+};
+
+// The result of a counting call leaves in 32 MiB slices through two pooled pinned blocks: slice i is written to the file (pwrite, host
+// threads) and / or copied to the caller's memory (host threads) while slice i + 1 crosses the link. A destination the caller pinned takes
+// one direct copy.
+static int download(void* host_dst, OutputFile* of, const void* d_src, uint64_t bytes, hipStream_t s, aix_ingest_stats_t* stats) {
     const double t0 = now_s();
     int st = AIX_OK;
-    if (out_path) {
-        const uint64_t slice = std::min<uint64_t>(bytes ? bytes : 1, 64ull << 20);
-        void* pin[2] = {nullptr, nullptr};
+    bool dst_pinned = false;
+    if (host_dst) {
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, host_dst) == hipSuccess) dst_pinned = (a.type == hipMemoryTypeHost); else (void)hipGetLastError();
+    }
+    if (host_dst && dst_pinned && bytes) {
+        if (hipMemcpyAsync(host_dst, d_src, bytes, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) st = AIX_ERR_HIP;
+    }
+    const bool staged = bytes && (of || (host_dst && !dst_pinned));
+    if (!st && staged) {
+        const uint64_t slice = std::min<uint64_t>(bytes, 32ull << 20);
+        void* pin[2] = {pinned_pool().get(slice), pinned_pool().get(slice)};
         hipEvent_t ev[2] = {nullptr, nullptr};
-        const int fd = ::open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
-        if (fd < 0) st = AIX_ERR_IO;
-        if (!st && bytes && ftruncate(fd, (off_t)bytes) != 0) st = AIX_ERR_IO;
-        for (int b = 0; b < 2 && !st; ++b) {
-            if (hipHostMalloc(&pin[b], slice, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); st = AIX_ERR_NOMEM; }
-            else if (hipEventCreateWithFlags(&ev[b], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); st = AIX_ERR_HIP; }
-        }
+        if (!pin[0] || !pin[1]) st = AIX_ERR_NOMEM;
+        for (int b = 0; b < 2 && !st; ++b)
+            if (hipEventCreateWithFlags(&ev[b], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); st = AIX_ERR_HIP; }
         const uint64_t nsl = (bytes + slice - 1) / slice;
         auto issue = [&](uint64_t i) -> int {
             const uint64_t lo = i * slice, m = std::min(slice, bytes - lo);
             if (hipMemcpyAsync(pin[i & 1], (const char*)d_src + lo, m, hipMemcpyDeviceToHost, s) != hipSuccess || hipEventRecord(ev[i & 1], s) != hipSuccess) return AIX_ERR_HIP;
             return AIX_OK;
         };
-        if (!st && nsl) st = issue(0);
+        if (!st) st = issue(0);
+        if (of) of->ready();
         for (uint64_t i = 0; i < nsl && !st; ++i) {
-            if (i + 1 < nsl) st = issue(i + 1);
-            if (!st && hipEventSynchronize(ev[i & 1]) != hipSuccess) st = AIX_ERR_HIP;
-            if (st) break;
+            if (hipEventSynchronize(ev[i & 1]) != hipSuccess) { st = AIX_ERR_HIP; break; }
+            if (i + 1 < nsl) { st = issue(i + 1); if (st) break; }
             const uint64_t lo = i * slice, m = std::min(slice, bytes - lo);
             const char* from = (const char*)pin[i & 1];
             std::atomic<int> bad{0};
+            const int fd = of ? of->fd : -1;
+            char* mem = (host_dst && !dst_pinned) ? (char*)host_dst + lo : nullptr;
             host_workers().sliced(m, [&](uint64_t a, uint64_t b) {
-                while (a < b) {
+                if (mem) memcpy(mem + a, from + a, b - a);
+                while (fd >= 0 && a < b) {
                     const ssize_t r = pwrite(fd, from + a, b - a, (off_t)(lo + a));
                     if (r <= 0) { bad = 1; return; }
                     a += (uint64_t)r;
                 }
             });
             if (bad) st = AIX_ERR_IO;
-            if (!st && host_dst) memcpy((char*)host_dst + lo, from, m);
         }
         (void)hipStreamSynchronize(s);
-        for (int b = 0; b < 2; ++b) { if (pin[b]) (void)hipHostFree(pin[b]); if (ev[b]) (void)hipEventDestroy(ev[b]); }
-        if (fd >= 0 && ::close(fd) != 0 && !st) st = AIX_ERR_IO;
-        if (st == AIX_ERR_HIP) set_last_error("result download failed");
-    } else if (host_dst && bytes) {
-        if (hipMemcpyAsync(host_dst, d_src, bytes, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
-            set_last_error("result download failed");
-            st = AIX_ERR_HIP;
-        }
+        for (int b = 0; b < 2; ++b) { pinned_pool().put(pin[b], slice); if (ev[b]) (void)hipEventDestroy(ev[b]); }
+    } else if (!st && of && host_dst && bytes) {                 // pinned destination and a file: the file is written from the caller's copy
+        of->ready();
+        std::atomic<int> bad{0};
+        const int fd = of->fd;
+        host_workers().sliced(bytes, [&](uint64_t a, uint64_t b) {
+            while (a < b) {
+                const ssize_t r = pwrite(fd, (const char*)host_dst + a, b - a, (off_t)a);
+                if (r <= 0) { bad = 1; return; }
+                a += (uint64_t)r;
+            }
+        });
+        if (bad) st = AIX_ERR_IO;
     }
+    if (of) { const int c = of->close_file(); if (!st) st = c; }
+    if (st == AIX_ERR_HIP) set_last_error("result download failed");
     if (stats) stats->seconds_output += now_s() - t0;
     return st;
 }
@@ -505,6 +612,8 @@ static int count13_any(aix_index_t* h, const ByteSource& src, int format, const 
     const double t0 = now_s();
     if (stats) memset(stats, 0, sizeof(*stats));
     DevGuard g(h->device);
+    OutputFile of;
+    if (out_path) { const int os_ = of.open_and_reserve(out_path, 8 * AIX_TOTAL_13MERS); if (os_) return os_; }
     hipStream_t s = nullptr;
     HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     int st;
@@ -513,12 +622,21 @@ static int count13_any(aix_index_t* h, const ByteSource& src, int format, const 
         st = dout.alloc(8 * AIX_TOTAL_13MERS) == hipSuccess ? AIX_OK : AIX_ERR_NOMEM;
         if (!st) st = count13_source(h, src, format, (uint64_t*)dout.p, s, stats);
         if (!st && hipStreamSynchronize(s) != hipSuccess) st = AIX_ERR_HIP;
-        if (!st) st = download(tf_out, out_path, dout.p, 8 * AIX_TOTAL_13MERS, s, stats);
+        if (!st) st = download(tf_out, out_path ? &of : nullptr, dout.p, 8 * AIX_TOTAL_13MERS, s, stats);
         if (stats) stats->device_bytes += 8 * AIX_TOTAL_13MERS;
     }
     (void)hipStreamDestroy(s);
     if (stats) stats->seconds_total = now_s() - t0;
     return st;
+}
+
+extern "C" int aix_ingest_warm(int device) {
+    int c = 0;
+    const int st = aix_device_count(&c);
+    if (st) return st;
+    if (device < 0 || device >= c) return AIX_ERR_ARG;
+    pinned_warm(device);
+    return AIX_OK;
 }
 
 extern "C" int aix_count13_file(aix_index_t* h, const char* path, int format, const char* out_path, uint64_t* tf_out, aix_ingest_stats_t* stats) {
@@ -552,7 +670,7 @@ static int count23_any(aix_index_t* h, const ByteSource& src, int format, int ca
         st = dout.alloc(4 * h->n) == hipSuccess ? AIX_OK : AIX_ERR_NOMEM;
         if (!st && hipMemsetAsync(dout.p, 0, 4 * h->n, s) != hipSuccess) st = AIX_ERR_HIP;
         if (!st) st = count23_source(h, src, format, canon_mode, (uint32_t*)dout.p, s, stats);
-        if (!st) st = download(tf_out, nullptr, dout.p, 4 * h->n, s, stats);
+        if (!st) st = download(tf_out, (OutputFile*)nullptr, dout.p, 4 * h->n, s, stats);
         if (stats) stats->device_bytes += 4 * h->n;
     }
     (void)hipStreamDestroy(s);

@@ -51,7 +51,7 @@ public:
     const int device;
     // statistics (read after the last next())
     uint64_t bytes_in = 0, parts = 0, pinned_bytes = 0, device_bytes = 0;
-    double seconds_read = 0, seconds_wait = 0;
+    double seconds_read = 0, seconds_wait = 0, seconds_h2d = 0;
 
 private:
     void produce();
@@ -59,7 +59,7 @@ private:
     uint8_t* direct = nullptr;
     void* pin[NB] = {};
     uint8_t* dbuf[NB] = {};
-    hipEvent_t h2d_ev[NB] = {}, used_ev[NB] = {};
+    hipEvent_t h2d_ev[NB] = {}, h2d_t0[NB] = {}, used_ev[NB] = {};
     hipStream_t copy_stream = nullptr;
     Part meta[NB] = {};
     std::thread producer;
@@ -71,6 +71,8 @@ private:
 };
 
 uint64_t ingest_part_bytes();
+void pinned_trim();
+void pinned_warm(int device);
 int upload_pipelined(const ByteSource& src, uint8_t* d_dst, int device, hipStream_t s);
 
 // Consumer side: the source as a sequence of PLAIN parts with the carry in front (see aix_ingest.hip)

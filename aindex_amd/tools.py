@@ -33,8 +33,19 @@ def count_kmers13(argv) -> int:
     if len(argv) < 3:
         print("Usage: count_kmers13 <input_file> <hash_file> <output_tf_file> [num_threads]", file=sys.stderr)
         return 1
+    import os
+    import time
+    t0 = time.perf_counter()
+    lib().aix_ingest_warm(0)                                            # library load; the staging blocks are pinned while the index opens
+    t1 = time.perf_counter()
     with Index.open_13(argv[1], None) as ix:                           # the input is streamed by the library: file -> pinned parts -> HBM -> table -> file
-        ix.count13_file(argv[0], argv[2], _lib.FMT_AUTO, want_array=False)
+        t2 = time.perf_counter()
+        _, st = ix.count13_file(argv[0], argv[2], _lib.FMT_AUTO, want_array=False)
+        t3 = time.perf_counter()
+    if os.environ.get("AIX_TOOL_TIMING"):
+        print(f"count_kmers13 timing: library {t1 - t0:.3f} s, index open {t2 - t1:.3f} s, count + write {t3 - t2:.3f} s "
+              f"(read {st['seconds_read']:.3f}, h2d {st['seconds_h2d']:.3f}, wait {st['seconds_wait']:.3f}, compute {st['seconds_compute']:.3f}, "
+              f"output {st['seconds_output']:.3f}), close {time.perf_counter() - t3:.3f} s", file=sys.stderr)
     return 0
 
 
@@ -53,6 +64,7 @@ def kmer_counter(argv) -> int:
         elif argv[i] == "--canon" and i + 1 < len(argv):
             canon = {"refx86": 1, "true": 2, "none": 0}[argv[i + 1]]; i += 1
         i += 1
+    lib().aix_ingest_warm(0)
     keys, counts, _ = counting.count_distinct_file(argv[0], k, canon, min_count, _lib.FMT_FASTA)      # streamed, never a whole-file bytes object
     order = np.argsort(-counts.astype(np.int64), kind="stable")       # count descending (ties: key ascending)
     ks = np.ascontiguousarray(keys[order], dtype=np.uint64)

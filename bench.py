@@ -184,8 +184,10 @@ def measure_e2e13(dev, cache, gigabytes, pf13, with_reference=True):
         # (2) the tool, as a process
         exe = os.path.join(ROOT, "bin", "count_kmers13")
         t0 = time.perf_counter()
-        r = subprocess.run([sys.executable, exe, p_plain, pf13, p_out, "16"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=900)
+        r = subprocess.run([sys.executable, exe, p_plain, pf13, p_out, "16"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=900,
+                           env=dict(os.environ, AIX_TOOL_TIMING="1"))
         dt = time.perf_counter() - t0
+        res["tool_phases"] = [ln for ln in r.stderr.decode().split("\n") if "timing" in ln][-1:]
         if r.returncode != 0:
             raise RuntimeError("bin/count_kmers13 failed: " + r.stderr.decode()[-300:])
         assert np.array_equal(np.fromfile(p_out, dtype=np.uint64), want), "tool output differs from the device-resident count"

@@ -239,9 +239,14 @@ typedef struct {
     double seconds_total;      /* wall clock of the call                                                   */
     double seconds_read;       /* file / page cache -> pinned staging (sum over parts, overlapped)         */
     double seconds_wait;       /* the consumer waited for a part to arrive                                 */
+    double seconds_h2d;        /* the parts on the link (HIP events around every copy, summed; the last three parts are not counted) */
     double seconds_compute;    /* normalise + count as seen by the host (includes the waits inside)        */
     double seconds_output;     /* result download + file write                                             */
 } aix_ingest_stats_t;
+/* Pin the staging blocks of a streaming call in the background and return at once (optional): a process that streams ONE file — a tool run —
+ * calls this before it opens its index, so that the ~100 ms of page pinning overlap the index load instead of delaying the first part.
+ * Staging blocks are kept between calls (AIX_PINNED_CACHE_MB, default 1024; aix_scratch_trim() frees them). */
+int aix_ingest_warm(int device);
 int aix_count13_file(aix_index_t* h, const char* path, int format, const char* out_path /* nullable */, uint64_t* tf_out /* nullable */,
                      aix_ingest_stats_t* stats);
 int aix_count23_fixed_file(aix_index_t* h, const char* path, int format, int canon_mode, uint32_t* tf_out /* u32[n] */, aix_ingest_stats_t* stats);
