@@ -492,6 +492,8 @@ extern "C" int aix_index_info(const aix_index_t* h, aix_info_t* info) {
     info->absence_filter_words = (h->bk && h->bk_enabled && h->bloom && h->bloom_enabled) ? h->nbloom : 0;
     info->minimizer_lines = (h->bk && h->bk_enabled && h->mk && h->mk_enabled) ? h->nbm : 0;
     info->minimizer_unfiled_keys = h->mk_unfiled;
+    info->count23_backend = h->c23_backend;
+    info->count23_passes = h->c23_passes;
     return AIX_OK;
 }
 
@@ -778,16 +780,20 @@ extern "C" int aix_count23_fixed_dev(aix_index_t* h, const char* d_plain, uint64
     if (nwin == 0 || h->n == 0) return AIX_OK;
     // Two back ends, same result. (a) one memory-side atomic per found window: ~23 G scattered atomics/s on MI355X, which bounds the
     // kernel once a probe costs a single line. (b) the slots are streamed out (4 B per window) and added into tf[] by the
-    // chunked-partition + LDS histogram of the 13-mer counter: no global atomics at all. (b) needs slots < 2^26 (2048 partitions of
-    // 32 768 bins) and pays a fixed cost, so short buffers keep (a). AIX_COUNT23_ATOMICS=1 forces (a); AIX_COUNT23_HIST_MIN moves
+    // chunked-partition + LDS histogram of the 13-mer counter: no global atomics at all. (b) handles 2^26 slots per pass over the slot
+    // stream (2048 partitions of 32 768 bins; a larger key set takes ceil(n / 2^26) passes) and pays a fixed cost, so short buffers keep
+    // (a). Which one ran is reported by aix_index_info (count23_backend / count23_passes). AIX_COUNT23_ATOMICS=1 forces (a); AIX_COUNT23_HIST_MIN moves
     // the threshold (tests run (b) on small inputs).
     uint64_t hist_min = 1ull << 22;
     if (const char* e = getenv("AIX_COUNT23_HIST_MIN")) hist_min = strtoull(e, nullptr, 10);
-    const bool use_hist = h->n <= (1ull << 26) && nwin >= hist_min && getenv("AIX_COUNT23_ATOMICS") == nullptr;
+    const bool use_hist = nwin >= hist_min && getenv("AIX_COUNT23_ATOMICS") == nullptr;
     if (!use_hist) {
         HIPCHK(launch_count23_fixed(h->dev(), (const uint8_t*)d_plain, len, canon_mode, d_tf_out, s));
+        h->c23_backend = 1; h->c23_passes = 0;
         return AIX_OK;
     }
+    uint32_t range_bits = 26;                                                  // AIX_COUNT23_TEST_RANGE_BITS: test hook, several slot ranges on a small key set
+    if (const char* e = getenv("AIX_COUNT23_TEST_RANGE_BITS")) { const int v = atoi(e); if (v >= 4 && v <= 26) range_bits = (uint32_t)v; }
     std::lock_guard<std::mutex> lk(h->count_mutex);
     if (h->work13_done) HIPCHK(hipStreamWaitEvent(s, h->work13_done, 0));
     else HIPCHK(hipEventCreateWithFlags(&h->work13_done, hipEventDisableTiming));
@@ -851,7 +857,9 @@ extern "C" int aix_count23_fixed_dev(aix_index_t* h, const char* d_plain, uint64
         } else {
             HIPCHK(launch_probe23_slots(dc, (const uint8_t*)d_plain + first, w + 22, canon_mode, slots, s));
         }
-        HIPCHK(launch_histogram_slots(slots, w, h->work13, d_tf_out, h->n, s));
+        uint32_t passes = 0;
+        HIPCHK(launch_histogram_slots(slots, w, h->work13, d_tf_out, h->n, s, range_bits, &passes));
+        h->c23_backend = 2; h->c23_passes = passes;
         if (overlap) HIPCHK(hipEventRecord(h->hist_ev[ip & 1], s));
     }
     uint32_t dropped = 0;

@@ -137,22 +137,27 @@ template <int TB>
 struct RunSlots {                                     // element j of this lane = p[j * TB]: every load instruction of the workgroup reads 4 * TB bytes of
     const uint32_t* p;                                // consecutive slots. Nothing is kept in registers between the two passes of the tile sort
     uint32_t limit;                                   // (WPT more live registers spill): the second pass re-reads the tile through L2
+    uint32_t base, range;                             // this pass adds the slots of [base, base + range), range <= 2^26; the others are somebody else's
     template <int J>
     __device__ __forceinline__ void get(uint32_t& c, uint32_t& ok) const {
         const uint32_t v = (uint32_t)(J * TB) < limit ? p[J * TB] : 0xFFFFFFFFu;
-        c = v & 0x3FFFFFFu;
-        ok = v != 0xFFFFFFFFu ? 1u : 0u;
+        const uint32_t r = v - base;
+        c = r & 0x3FFFFFFu;
+        ok = (v != 0xFFFFFFFFu && r < range) ? 1u : 0u;
     }
 };
-struct SrcSlots {                                     // a stream of MPHF slots (< 2^26) in HBM, 0xFFFFFFFF = nothing to count (count23)
+struct SrcSlots {                                     // a stream of MPHF slots in HBM, 0xFFFFFFFF = nothing to count (count23); one pass per 2^26 slots of the key set
     const uint32_t* slots;
     uint64_t n;
+    uint32_t base, range;
     template <int TB, int WPT>
     __device__ __forceinline__ RunSlots<TB> fetch(uint64_t tile, int t) const {  // nothing is fetched ahead: the passes read the stream themselves
         const uint64_t base = tile * (uint64_t)(TB * WPT) + (uint64_t)t;
         RunSlots<TB> r;
         r.p = slots + base;
         r.limit = base < n ? (uint32_t)min((uint64_t)(TB * WPT), n - base) : 0u;  // elements [0, limit) of p are inside the stream
+        r.base = this->base;
+        r.range = range;
         return r;
     }
     template <int TB, int WPT>
@@ -455,11 +460,23 @@ hipError_t launch_count13_partitioned(const uint8_t* buf, uint64_t len, void* wo
     return partitioned_histogram(Src13{buf, len}, nwin, workspace, table, perm, out_mphf, accumulate, nullptr, 0, s);
 }
 
-// count23 back end: tf_out[slot] += occurrences of slot in d_slots[0, nslots) (0xFFFFFFFF entries are skipped); every slot < 2^26.
-// Same workspace layout as the 13-mer counter (count13_workspace_bytes(nslots + 12)).
-hipError_t launch_histogram_slots(const uint32_t* d_slots, uint64_t nslots, void* workspace, uint32_t* tf_out, uint64_t n, hipStream_t s) {
-    if (nslots == 0) return hipSuccess;
-    return partitioned_histogram(SrcSlots{d_slots, nslots}, nslots, workspace, nullptr, nullptr, nullptr, 1, tf_out, n, s);
+// count23 back end: tf_out[slot] += occurrences of slot in d_slots[0, nslots) (0xFFFFFFFF entries are skipped). The partitions hold 26-bit
+// values (2 048 partitions of 32 768 bins), so a key set of more than `range` (2^26) slots takes one pass over the slot stream per range of
+// slots — the stream is 4 bytes per window and a pass only sorts the windows of its own range, so P passes cost little more than one.
+// Same workspace layout as the 13-mer counter (count13_workspace_bytes(nslots + 12)). *passes_out: passes made.
+hipError_t launch_histogram_slots(const uint32_t* d_slots, uint64_t nslots, void* workspace, uint32_t* tf_out, uint64_t n, hipStream_t s, uint32_t range_bits,
+                                  uint32_t* passes_out) {
+    if (passes_out) *passes_out = 0;
+    if (nslots == 0 || n == 0) return hipSuccess;
+    if (range_bits < 4 || range_bits > 26) range_bits = 26;
+    const uint64_t range = 1ull << range_bits;
+    for (uint64_t base = 0; base < n; base += range) {
+        const uint64_t m = std::min(range, n - base);
+        const hipError_t e = partitioned_histogram(SrcSlots{d_slots, nslots, (uint32_t)base, (uint32_t)m}, nslots, workspace, nullptr, nullptr, nullptr, 1, tf_out + base, m, s);
+        if (e != hipSuccess) return e;
+        if (passes_out) ++*passes_out;
+    }
+    return hipSuccess;
 }
 
 }  // namespace aix

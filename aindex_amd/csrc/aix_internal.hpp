@@ -74,9 +74,9 @@ uint64_t count13_workspace_bytes(uint64_t len);
 // perm/out_mphf set: counters are written straight into the (pre-zeroed) mphf-ordered output; else into table_code
 hipError_t launch_count13_partitioned(const uint8_t* buf, uint64_t len, void* workspace, unsigned long long* table_code, const uint32_t* perm,
                                       uint64_t* out_mphf, int accumulate, hipStream_t s);
-// count23 without global atomics: tf_out[slot] += occurrences of slot in the stream (slots < 2^26, 0xFFFFFFFF = skip)
+// count23 without global atomics: tf_out[slot] += occurrences of slot in the stream (0xFFFFFFFF = skip); one pass per 2^26 slots of the key set
 hipError_t launch_histogram_slots(const uint32_t* d_slots, uint64_t nslots, void* workspace /* count13_workspace_bytes(nslots + 12) */, uint32_t* tf_out,
-                                  uint64_t n, hipStream_t s);
+                                  uint64_t n, hipStream_t s, uint32_t range_bits = 26 /* slots per pass = 2^range_bits <= 2^26 */, uint32_t* passes_out = nullptr);
 // the same slot stream from the minimizer-keyed table (aix_stream23.hip): a lane owns 32 consecutive windows; needs ix.mk
 hipError_t launch_stream23_slots(const IndexDev& ix, const uint8_t* buf, uint64_t len, int canon_mode, uint32_t* slots /* [len - 22] */,
                                  uint32_t* flag /* zeroed word: set when a window stayed undecided */, hipStream_t s);

@@ -67,6 +67,39 @@ def all_reduce_sum_(t):
     return t
 
 
+def all_reduce_sum_u64_narrow_(t):
+    """In-place sum over ranks of a table of u64 counters carried as int64 (the 4^13 table of count_kmers13: 512 MiB), sent as u32 when
+    that is exact. Every global counter is at most the sum over ranks of the ranks' largest local counter; ONE 8-byte all-reduce of
+    those maxima decides: below 2^32 the table crosses the links as int32 (u32 bit patterns, 256 MiB, addition modulo 2^32 is then the
+    true sum) and is widened back, otherwise it goes as int64. Returns (t, bits) with bits = 32 or 64 (0: no process group)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("AIX_FORCE_DIST"))):
+        return t, 0
+    via_host = t.is_cuda and dist.get_backend() != "nccl"
+    m = (t.max() if t.numel() else torch.zeros((), dtype=torch.int64, device=t.device)).reshape(1).to(torch.float64)   # counts < 2^53 here: exact in f64, and the sum cannot wrap
+    negative = bool((t.min() < 0).item()) if t.numel() else False                                                          # a counter above 2^63 - 1: leave it to the wide path
+    flag = torch.tensor([m.item(), 1.0 if negative else 0.0], dtype=torch.float64, device="cpu" if via_host else t.device)
+    dist.all_reduce(flag, op=dist.ReduceOp.SUM)
+    if flag[0].item() < float(1 << 32) and flag[1].item() == 0.0:
+        t32 = torch.where(t >= (1 << 31), t - (1 << 32), t).to(torch.int32)
+        if via_host:
+            h = t32.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            t32 = h.to(t.device)
+        else:
+            dist.all_reduce(t32, op=dist.ReduceOp.SUM)
+        t.copy_(t32.to(torch.int64) & 0xFFFFFFFF)
+        return t, 32
+    if via_host:
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t, 64
+
+
 def barrier():
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("AIX_FORCE_DIST")):
@@ -93,7 +126,7 @@ def count13_sharded(index, plain: bytes, device=None):
     mine = shard_lines(plain, rank, world)
     t = torch.frombuffer(bytearray(mine) if mine else bytearray(1), dtype=torch.uint8)[: len(mine)].to(f"cuda:{dev}")
     out = index.count13_t(t)
-    return all_reduce_sum_(out)
+    return all_reduce_sum_u64_narrow_(out)[0]
 
 
 def count23_sharded(index, plain: bytes, canon_mode: int = 2, device=None):
@@ -112,9 +145,10 @@ def count23_sharded(index, plain: bytes, canon_mode: int = 2, device=None):
 def count13_sharded_t(index, plain_t, out_t=None):
     """Device-tensor twin of count13_sharded: `plain_t` is THIS rank's record-aligned share of the reads, already in HBM
     (uint8 tensor on the index's device) — nothing is uploaded from host memory. Counts it and all-reduces the 4^13 table
-    in place (RCCL under "nccl"). Returns the int64 tensor [4^13] (mphf order) with the global counts on every rank."""
+    in place (RCCL under "nccl"; as u32 — 256 MiB instead of 512 — whenever no counter can reach 2^32, all_reduce_sum_u64_narrow_).
+    Returns the int64 tensor [4^13] (mphf order) with the global counts on every rank."""
     out_t = index.count13_t(plain_t, out_t)
-    return all_reduce_sum_(out_t)
+    return all_reduce_sum_u64_narrow_(out_t)[0]
 
 
 def count23_sharded_t(index, plain_t, canon_mode: int = 2, out_t=None):
@@ -508,17 +542,34 @@ def positions_fill_sharded_t(index, shard_t, base_offset: int, merge: str = "all
         except Exception as e:
             err = e
     _raise_together(err, "positions_fill_sharded_t (fill)", cdev)
-    if merge == "scatter" and active and world > 1:
+    mine, bounds = merge_positions_(pos, total, merge, rank, world)
+    return indices, mine, bounds
+
+
+def scatter_slice_bounds(total: int, rank: int, world: int):
+    """merge="scatter": the positions array (total entries) is padded to per * world entries, per = ceil(total / world); rank r keeps
+    entries [lo, hi) = [min(r * per, total), min(lo + per, total)) — empty for the ranks past the end."""
+    per = (total + world - 1) // world
+    lo = min(rank * per, total)
+    return per, lo, min(lo + per, total)
+
+
+def merge_positions_(pos, total: int, merge: str, rank: int, world: int):
+    """Merge of the full-size partial positions arrays (one writer per entry, zero elsewhere). pos: max(per * world, 1) entries for
+    merge="scatter", max(total, 1) for "all". Returns (this rank's entries, (lo, hi))."""
+    import torch
+    import torch.distributed as dist
+    if merge == "scatter" and _active() and world > 1:
+        per, lo, hi = scatter_slice_bounds(total, rank, world)
         if _backend_is_nccl():
-            mine = torch.empty(per, dtype=torch.int64, device=dev)
-            dist.reduce_scatter_tensor(mine, pos, op=dist.ReduceOp.SUM)
+            mine = torch.empty(max(per, 1), dtype=pos.dtype, device=pos.device)[:per]
+            if per:
+                dist.reduce_scatter_tensor(mine, pos[: per * world], op=dist.ReduceOp.SUM)
         else:                                                # gloo has no reduce-scatter: the rehearsal sums everything and cuts
             mine = _all_reduce_(pos, "sum")[rank * per:(rank + 1) * per]
-        lo = min(rank * per, total)
-        hi = min(lo + per, total)
-        return indices, mine[: hi - lo], (lo, hi)
+        return mine[: hi - lo], (lo, hi)
     _all_reduce_(pos, "sum")                                # every entry is written by exactly one rank
-    return indices, pos[:total], (0, total)
+    return pos[:total], (0, total)
 
 
 def _u32_bits(t64):

@@ -64,6 +64,9 @@ typedef struct {
     uint32_t absence_filter_words; /* 64-bit words of the absence filter in front of the table (0: off) */
     uint64_t minimizer_lines;     /* 128-byte lines of the minimizer-keyed copy of the table (0: off)   */
     uint64_t minimizer_unfiled_keys; /* keys whose chain of lines was full (answered by the hash-keyed table) */
+    uint32_t count23_backend; /* the last aix_count23_fixed* call on this handle: 0 none yet, 1 memory-side atomics (short buffers,
+                                 AIX_COUNT23_ATOMICS=1), 2 slot stream + LDS histogram                                              */
+    uint32_t count23_passes;  /* back end 2: passes over the slot stream = ceil(n / 2^26)                                           */
 } aix_info_t;
 
 const char* aix_version(void);

@@ -34,6 +34,17 @@ def test_two_rank_gloo_counting_and_queries():
     assert r.returncode == 0 and "DIST_OK" in out, out[-3000:]
 
 
+def test_three_rank_gloo_with_an_empty_share_and_slice_arithmetic():
+    """More ranks than reads: the rank with nothing to count joins every collective (counting all-reduce, the narrow 13-mer reduce,
+    the K1 exchange), and the scatter-merge slice bounds hold for totals of 0, < world and not divisible by it (_dist_empty_worker.py)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1",
+           "--master-port", "29679", os.path.join(ROOT, "tests", "_dist_empty_worker.py")]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0 and "DIST_EMPTY_OK" in out, out[-3000:]
+
+
 def test_bench_gpus_n_starts_its_own_ranks():
     """`python bench.py --gpus N` outside a torchrun environment launches the N ranks itself (child processes, rendezvous on
     127.0.0.1), hands their ONE JSON line on with n_gpus = N and leaves with their status. The GPU-free `selftest` workload
@@ -60,7 +71,7 @@ def test_device_tensor_sharded_counters_exist():
     for name in ("count23_sharded_t", "count13_sharded_t"):
         fn = getattr(adist, name)
         src = inspect.getsource(fn)
-        assert "all_reduce_sum_" in src and "frombuffer" not in src and ".to(" not in src
+        assert "all_reduce_sum_" in src and "frombuffer" not in src and ".to(" not in src     # (count13: all_reduce_sum_u64_narrow_)
 
 
 def test_exchange_merge_single_process_and_owner_hash():

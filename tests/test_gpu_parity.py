@@ -1544,6 +1544,7 @@ def test_count23_histogram_backend_equals_atomics_and_oracle(canon_case, small23
                 want = o.count23_fixed(buf, False, mode)
                 monkeypatch.setenv("AIX_COUNT23_ATOMICS", "1")
                 assert np.array_equal(ix.count23_fixed(buf, _lib.FMT_PLAIN, mode), want)
+                assert ix.info["count23_backend"] == 1
                 monkeypatch.delenv("AIX_COUNT23_ATOMICS")
                 monkeypatch.setenv("AIX_COUNT23_HIST_MIN", "0")
                 for piece in (None, "1000", "77777"):
@@ -1560,6 +1561,14 @@ def test_count23_histogram_backend_equals_atomics_and_oracle(canon_case, small23
                     monkeypatch.setenv("AIX_COUNT23_OVERLAP", "0")
                     assert np.array_equal(ix.count23_fixed(buf, _lib.FMT_PLAIN, mode), want), (mode, piece, "one stream")
                     monkeypatch.delenv("AIX_COUNT23_OVERLAP")
+                    # a key set beyond the 2^26 slots one pass of the histogram back end holds takes ceil(n / range) passes over the
+                    # slot stream (range shrunk to 2^10 ... 2^14 slots here so that these small key sets need 2 ... 300 of them)
+                    assert ix.info["count23_backend"] == 2 and ix.info["count23_passes"] == 1
+                    for bits in ("10", "12", "14"):
+                        monkeypatch.setenv("AIX_COUNT23_TEST_RANGE_BITS", bits)
+                        assert np.array_equal(ix.count23_fixed(buf, _lib.FMT_PLAIN, mode), want), (mode, piece, "ranges", bits)
+                        assert ix.info["count23_backend"] == 2 and ix.info["count23_passes"] == -(-ix.n // (1 << int(bits)))
+                    monkeypatch.delenv("AIX_COUNT23_TEST_RANGE_BITS")
                 ix.set_bucket_table(True)
                 ix.set_minimizer_table(True)
                 monkeypatch.delenv("AIX_COUNT23_PIECE", raising=False)
