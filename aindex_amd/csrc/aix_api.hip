@@ -825,6 +825,13 @@ extern "C" int aix_count23_fixed_dev(aix_index_t* h, const char* d_plain, uint64
         piece = pw / 2;
     }
     uint32_t* slot_buf[2] = {(uint32_t*)((uint8_t*)h->work13 + part_bytes), (uint32_t*)((uint8_t*)h->work13 + part_bytes + (overlap ? slot_bytes : 0))};
+    // an error in the middle of the loop would return with the probe stream still writing into the workspace, and the event recorded on
+    // exit (caller's stream only) would let the next counting call in under it: a failing call waits for the probe stream first
+    struct ProbeDrainOnError {
+        aix_index* h;
+        bool armed = true;
+        ~ProbeDrainOnError() { if (armed && h->probe_stream) (void)hipStreamSynchronize(h->probe_stream); }
+    } probe_drain{h};
     HIPCHK(hipMemsetAsync(h->work13, 0, 4, s));                               // the error word of the partition workspace
     if (overlap) {
         if (!h->probe_stream) {
@@ -866,6 +873,7 @@ extern "C" int aix_count23_fixed_dev(aix_index_t* h, const char* d_plain, uint64
     HIPCHK(hipMemcpyAsync(&dropped, h->work13, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     if (dropped) { set_last_error("count23: chunk region exhausted (partition workspace undersized)"); return AIX_ERR_UNSUPPORTED; }
+    probe_drain.armed = false;                                                 // every probe has been waited for by a histogram on the caller's stream
     return AIX_OK;
 }
 
@@ -1018,6 +1026,11 @@ struct HostPipe {
 
 static void free_host_pipe(HostPipe* p) { delete p; }
 
+static uint64_t pipe_fail_chunk() {                       // test hook, read once: the chunk of a large host batch whose launch "fails"
+    static const uint64_t c = [] { const char* e = getenv("AIX_PIPE_TEST_FAIL_CHUNK"); return e ? strtoull(e, nullptr, 10) : ~0ull; }();
+    return c;
+}
+
 // in: N elements of in_elem bytes each (host); outs[j]: N elements of out_elem[j] bytes (host, nullable). call(d_in, m, d_out0..2, stream).
 template <typename F>
 static int pipelined_host_batch(aix_index_t* h, const char* in, uint32_t in_elem, uint64_t N, const uint32_t out_elem[3], void* const outs[3], F&& call) {
@@ -1031,6 +1044,13 @@ static int pipelined_host_batch(aix_index_t* h, const char* in, uint32_t in_elem
     HostPipe& P = *h->pipe;
     for (int j = 0; j < 3; ++j)
         if (outs[j]) { const int st = P.need_out(j); if (st) { (void)hipGetLastError(); return st; } }
+    // every exit but the last one leaves with copies / kernels possibly queued on the pipe's streams; they touch the handle's staging
+    // buffers (and caller-pinned outputs), which the next call reuses at once: a failing call drains the streams before it returns
+    struct DrainOnError {
+        HostPipe& P;
+        bool armed = true;
+        ~DrainOnError() { if (armed) for (int i = 0; i < HostPipe::S; ++i) (void)hipStreamSynchronize(P.st[i]); }
+    } drain_on_error{P};
     CopyPool& pool = copy_pool();
     // buffers the caller has already pinned (hipHostMalloc / hipHostRegister, e.g. torch pinned tensors) go over the wire as they
     // are; only pageable memory is staged through the pipe's own pinned buffers
@@ -1062,14 +1082,16 @@ static int pipelined_host_batch(aix_index_t* h, const char* in, uint32_t in_elem
             pool.copy(P.hin[b], in + lo * in_elem, m * in_elem);
             HIPCHK(hipMemcpyAsync(P.din[b], P.hin[b], m * in_elem, hipMemcpyHostToDevice, P.st[b]));
         }
-        const int st = call((const char*)P.din[b], m, P.dout[b][0], P.dout[b][1], P.dout[b][2], (void*)P.st[b]);
-        if (st) { for (int i = 0; i < HostPipe::S; ++i) (void)hipStreamSynchronize(P.st[i]); return st; }
+        int st = call((const char*)P.din[b], m, P.dout[b][0], P.dout[b][1], P.dout[b][2], (void*)P.st[b]);
+        if (!st && c == pipe_fail_chunk()) st = AIX_ERR_HIP;                  // AIX_PIPE_TEST_FAIL_CHUNK: fault injection (tests)
+        if (st) return st;
         for (int j = 0; j < 3; ++j)
             if (outs[j]) HIPCHK(hipMemcpyAsync(out_pinned[j] ? (void*)((char*)outs[j] + lo * out_elem[j]) : P.hout[b][j], P.dout[b][j], m * out_elem[j],
                                                hipMemcpyDeviceToHost, P.st[b]));
         HIPCHK(hipEventRecord(P.ev[b], P.st[b]));
     }
     for (uint64_t c = nchunks > (uint64_t)HostPipe::S ? nchunks - HostPipe::S : 0; c < nchunks; ++c) { const int st = drain(c); if (st) return st; }
+    drain_on_error.armed = false;
     return AIX_OK;
 }
 
@@ -1350,6 +1372,14 @@ static int upload_host(const char* buf, uint64_t len, uint8_t* d_dst, int device
     return AIX_OK;
 }
 
+// positions_fill refuses a 13-mer tf table with an entry above 2^32 - 1 (32-bit fill counters, aix_positions.hip): that is a status, not a HIP failure
+#define POSCHK(expr)                                                                                                                     \
+    do {                                                                                                                                 \
+        hipError_t _e = (expr);                                                                                                          \
+        if (_e == hipErrorNotSupported) { (void)hipGetLastError(); set_last_error("positions: a 13-mer tf above 2^32 - 1"); return AIX_ERR_UNSUPPORTED; } \
+        if (_e != hipSuccess) { set_last_error(std::string(#expr) + ": " + hipGetErrorString(_e)); return AIX_ERR_HIP; }                  \
+    } while (0)
+
 // first window the reference's single worker looks at (hash.cpp:973-986): the start is pushed past any
 // '\n', '~' or '?' found in the first k bytes, repeatedly
 static uint64_t a2_start(const char* c, uint64_t len, uint64_t k = 23) {
@@ -1387,7 +1417,7 @@ extern "C" int aix_positions_fill(aix_index_t* h, const char* reads, uint64_t le
     HIPCHK(dpos.alloc(8 * total));
     HIPCHK(hipMemsetAsync(dpos.p, 0, 8 * total, 0));
     { const int us = upload_host(reads, len, (uint8_t*)dreads.p, h->device); if (us) return us; }
-    HIPCHK(positions_fill(h->dev_slots(), (const uint8_t*)dreads.p, len, a2_start(reads, len, h->k), (const uint64_t*)dind.p, (uint64_t*)dpos.p, piece, nullptr, 0, 0));
+    POSCHK(positions_fill(h->dev_slots(), (const uint8_t*)dreads.p, len, a2_start(reads, len, h->k), (const uint64_t*)dind.p, (uint64_t*)dpos.p, piece, nullptr, 0, 0));
     HIPCHK(hipMemcpy(positions_out, dpos.p, 8 * total, hipMemcpyDeviceToHost));
     return AIX_OK;
 }
@@ -1423,7 +1453,7 @@ extern "C" int aix_positions_fill_dev(aix_index_t* h, const char* d_reads, uint6
     if (total == 0) return AIX_OK;
     if (!d_positions_out || positions_cap < total) return AIX_ERR_ARG;
     HIPCHK(hipMemsetAsync(d_positions_out, 0, 8 * total, s));
-    HIPCHK(positions_fill(h->dev_slots(), (const uint8_t*)d_reads, len, start, d_indices_out, d_positions_out, piece, nullptr, 0, s));
+    POSCHK(positions_fill(h->dev_slots(), (const uint8_t*)d_reads, len, start, d_indices_out, d_positions_out, piece, nullptr, 0, s));
     return AIX_OK;
 }
 
@@ -1477,7 +1507,7 @@ extern "C" int aix_positions_fill_shard(aix_index_t* h, const char* reads, uint6
     }
     { const int us = upload_host(reads, len, (uint8_t*)dreads.p, h->device); if (us) return us; }
     HIPCHK(hipMemset(dpos.p, 0, 8 * total));
-    HIPCHK(positions_fill(h->dev_slots(), (const uint8_t*)dreads.p, len, first_shard ? a2_start(reads, len, h->k) : 0, (const uint64_t*)dind.p, (uint64_t*)dpos.p, piece,
+    POSCHK(positions_fill(h->dev_slots(), (const uint8_t*)dreads.p, len, first_shard ? a2_start(reads, len, h->k) : 0, (const uint64_t*)dind.p, (uint64_t*)dpos.p, piece,
                           filled_init ? (const uint32_t*)dfill.p : nullptr, base_offset, 0));
     HIPCHK(hipMemcpy(positions_out, dpos.p, 8 * total, hipMemcpyDeviceToHost));
     return AIX_OK;
@@ -1527,7 +1557,7 @@ extern "C" int aix_positions_fill_shard_dev(aix_index_t* h, const char* d_reads,
     if (h->n == 0) return AIX_OK;
     uint64_t piece = 0;
     if (const char* e = getenv("AIX_POSITIONS_PIECE")) piece = strtoull(e, nullptr, 10);
-    HIPCHK(positions_fill(h->dev_slots(), (const uint8_t*)d_reads, len, start, d_indices, d_positions, piece, d_filled_init, base_offset, (hipStream_t)stream));
+    POSCHK(positions_fill(h->dev_slots(), (const uint8_t*)d_reads, len, start, d_indices, d_positions, piece, d_filled_init, base_offset, (hipStream_t)stream));
     return AIX_OK;
 }
 

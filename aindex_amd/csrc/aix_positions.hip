@@ -123,8 +123,16 @@ __global__ void __launch_bounds__(kB) k_tf13_copy(const uint64_t* __restrict__ t
     const uint64_t stride = (uint64_t)gridDim.x * kB;
     for (uint64_t i = (uint64_t)blockIdx.x * kB + threadIdx.x; i <= n; i += stride) out[i] = i < n ? tf[i] : 0ull;
 }
-// after a piece has been placed: filled[h] += occurrences of h in the piece (saturating; tf is 32 bits, so a saturated
-// counter can never admit another offset). One writer per bucket: the lane that holds the last element of h's run.
+// after a piece has been placed: filled[h] += occurrences of h in the piece (saturating). The counters are u32: for 23-mers tf is 32 bits
+// (.tf.bin), so a saturated counter can never admit another offset; a 13-mer table is u64, and positions_fill REFUSES a table with an entry
+// above 2^32 - 1 (hipErrorNotSupported -> AIX_ERR_UNSUPPORTED) instead of letting a saturated counter overwrite earlier slots.
+// One writer per bucket: the lane that holds the last element of h's run.
+__global__ void __launch_bounds__(kB) k_tf13_above_u32(const uint64_t* __restrict__ tf, uint64_t n, uint32_t* __restrict__ flag) {
+    const uint64_t stride = (uint64_t)gridDim.x * kB;
+    bool any = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * kB + threadIdx.x; i < n; i += stride) any |= (tf[i] >> 32) != 0;
+    if (any) *flag = 1u;
+}
 __global__ void __launch_bounds__(kB) k_a2_advance(const uint32_t* __restrict__ skeys, uint64_t nwin, uint32_t n, const uint32_t* __restrict__ first,
                                                   uint32_t* __restrict__ filled) {
     const uint64_t stride = (uint64_t)gridDim.x * kB;
@@ -219,6 +227,18 @@ hipError_t positions_fill(const IndexDev& ix, const uint8_t* d_reads, uint64_t l
     const uint64_t nwin_all = len - (ix.k - 1);
     if (piece == 0 || piece > (1ull << 31)) piece = 1ull << 30;
     const uint64_t pw = std::min(piece, nwin_all);
+    if (ix.k == 13) {                                                           // the fill counters are 32 bits wide (see k_a2_advance)
+        uint32_t* d_flag = nullptr;
+        uint32_t flag = 0;
+        hipError_t ef = pool_alloc((void**)&d_flag, 4);
+        if (ef == hipSuccess) ef = hipMemsetAsync(d_flag, 0, 4, s);
+        if (ef == hipSuccess) { hipLaunchKernelGGL(k_tf13_above_u32, dim3(grid_of(ix.n)), dim3(kB), 0, s, ix.tf13_mphf, ix.n, d_flag); ef = hipGetLastError(); }
+        if (ef == hipSuccess) ef = hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, s);
+        { const hipError_t es = hipStreamSynchronize(s); if (ef == hipSuccess) ef = es; }
+        if (d_flag) pool_free(d_flag);
+        if (ef != hipSuccess) return ef;
+        if (flag) return hipErrorNotSupported;
+    }
     uint32_t *keys = nullptr, *skeys = nullptr, *svals = nullptr, *first = nullptr, *filled = nullptr;
     void* tmp = nullptr;
     hipError_t e = pool_alloc((void**)&keys, 4 * pw);

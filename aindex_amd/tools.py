@@ -5,7 +5,7 @@
     python -m aindex_amd.tools compute_mphf_seq <keys.txt> [out.pf]
     python -m aindex_amd.tools compute_index <dat> <pf> <prefix> <threads> <mock>
     python -m aindex_amd.tools compute_aindex <reads> <pf> <prefix> <threads> 23 <tf> <kmers.bin> <kmers.txt> [index.bin indices.bin]
-    python -m aindex_amd.tools compute_aindex13 <reads> <pf> <tf.bin> <prefix> <threads> [pos_bin] [index.bin] [indices.bin]
+    python -m aindex_amd.tools compute_aindex13 <reads> <pf> <tf.bin> <prefix> <threads> [pos_bin] [index.bin] [indices.bin] [--tf-u32]
     python -m aindex_amd.tools compute_reads <file1> <file2|-> <fastq|fasta|se|reads> <prefix>     (host-side, no GPU)
 
 `threads` arguments are accepted and ignored (the work runs on the GPU). Exit status 0 on success.
@@ -167,15 +167,25 @@ def compute_aindex(argv) -> int:
 def compute_aindex13(argv) -> int:
     """compute_aindex13.cpp:323-409: <reads> <pf> <tf.bin> <prefix> <threads> [pos_bin] [index_bin] [indices_bin] (the optional
     names are argv[7] / argv[8] there, :343-344). N3: positions index of the 13-mers, forward strand, tf = the u64[4^13]
-    table count_kmers13 wrote (the reference tool misreads that file as u32, compute_aindex13.cpp:46-47)."""
+    table count_kmers13 wrote. DIVERGENCE FROM THE REFERENCE BINARY, on purpose: that tool reads the u64 file as u32[4^13]
+    (compute_aindex13.cpp:46-47) and so indexes a scrambled table; this one reads it as what it is, and its .index.bin / .indices.bin therefore
+    differ from the reference tool's for the same inputs. `--tf-u32` (anywhere on the command line) or AIX_REF_COMPAT=1 selects the
+    reference's reading and reproduces its files byte for byte (tests/golden/aindex13)."""
     if len(argv) < 5:
         print("Expected arguments: compute_aindex13 <reads_file> <hash_file> <tf_file> <output_prefix> <num_threads> [pos_bin] [index_bin] [indices_bin]",
               file=sys.stderr)
         return 1
+    import os
+    ref_compat = "--tf-u32" in argv or os.environ.get("AIX_REF_COMPAT") == "1"
+    argv = [x for x in argv if x != "--tf-u32"]
     reads_file, pf, tf_file, prefix = argv[:4]
     index_bin = argv[6] if len(argv) > 6 else prefix + ".index.bin"
     indices_bin = argv[7] if len(argv) > 7 else prefix + ".indices.bin"
-    with Index.open_13(pf, tf_file) as ix:
+    with Index.open_13(pf, None if ref_compat else tf_file) as ix:
+        if ref_compat:
+            # the reference binary reads the first 4^13 u32 WORDS of the tf file (compute_aindex13.cpp:46-47: the u64 file of its own
+            # count_kmers13 misread); `--tf-u32` / AIX_REF_COMPAT=1 indexes exactly that table and so writes the reference's files
+            ix.set_tf_13(np.fromfile(tf_file, dtype=np.uint32, count=_lib.TOTAL_13MERS).astype(np.uint64))
         indices, pos = ix.positions_fill(_mapped(reads_file))
     pos.tofile(index_bin)
     indices.tofile(indices_bin)

@@ -158,20 +158,24 @@ class AindexWrapper:
         if reads_file and getattr(self, "_reads", None) is None:
             self.load_reads(reads_file)
 
-    def load_13mer_aindex(self, index_file: str, indices_file: str):
+    def load_13mer_aindex(self, index_file: str, indices_file: str, ref_compat: bool = False):
         """:439-471. The reference maps only `.indices.bin` here and never sets `positions_13mer`, so its 13-mer position
         queries always answer []; the mirror maps BOTH files (the `.index.bin` our compute_aindex13 writes, N3) so that
         get_positions_13mer (:1070-1100) can answer what it is written to answer. A missing index file keeps the reference's
-        behaviour (indices only, queries return [])."""
+        behaviour (indices only, queries return []), and so does ref_compat=True (or AIX_REF_COMPAT=1): the positions file is
+        not mapped and every get_positions_13mer answers [] as the reference's does."""
         self._need(indices_file)
         self._indices13 = np.memmap(indices_file, dtype=np.uint64, mode="r")
         self._positions13 = None
+        if ref_compat or os.environ.get("AIX_REF_COMPAT") == "1":
+            self.aindex_loaded = True
+            return
         if index_file and os.path.isfile(index_file) and os.path.getsize(index_file):
             self._positions13 = np.memmap(index_file, dtype=np.uint64, mode="r")
         self.aindex_loaded = True
 
-    def load_aindex_from_prefix_13mer(self, prefix: str, reads_file: str = ""):
-        self.load_13mer_aindex(prefix + ".index.bin", prefix + ".indices.bin")
+    def load_aindex_from_prefix_13mer(self, prefix: str, reads_file: str = "", ref_compat: bool = False):
+        self.load_13mer_aindex(prefix + ".index.bin", prefix + ".indices.bin", ref_compat)
 
     def build_aindex(self, reads_file: str, prefix: Optional[str] = None):
         """compute_aindex replacement (A1/A2 on the GPU): returns (indices, positions) and, with a prefix,

@@ -273,7 +273,8 @@ int aix_window_codes_dev(const char* d_plain, uint64_t len, int k, int canon_mod
  * counts iff its 13 bytes are upper-case A/C/G/T, forward strand only, same slot rule and start adjustment. The reference tool
  * itself reads the u64 tf file as u32[4^13] (compute_aindex13.cpp:46-47) and therefore indexes a scrambled table; handing this
  * entry point that misread view (widened to u64) reproduces the reference's files bit for bit, which is how the path is pinned
- * (tests/golden/aindex13). All positions entry points below accept 13-mer handles in the same way. */
+ * (tests/golden/aindex13). All positions entry points below accept 13-mer handles in the same way; a 13-mer table with an entry
+ * above 2^32 - 1 is AIX_ERR_UNSUPPORTED (the per-bucket fill counters are 32 bits wide; the reference's are u64 fetch_adds). */
 int aix_positions_fill(aix_index_t* h, const char* reads, uint64_t len, uint64_t* indices_out, uint64_t* positions_out,
                        uint64_t positions_cap, uint64_t* total_out);
 /* device-resident twin (reads, indices and positions in HBM; returns after the fill has completed on `stream`):

@@ -15,6 +15,9 @@ from aindex_amd import _lib, builder, synth
 from aindex_amd.engine import Index
 
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
 def load(gold, *p):
     return json.load(open(os.path.join(gold, *p)))
 
@@ -1467,6 +1470,19 @@ def test_positions13_reference_pin_oracle_pieces_and_mirror(gold, tmp_path, monk
     assert r.returncode == 0, r.stderr[-2000:]
     assert np.array_equal(np.fromfile(prefix + ".index.bin", dtype=np.uint64), opos)
     assert np.array_equal(np.fromfile(prefix + ".indices.bin", dtype=np.uint64), oind)
+    # the reference binary's own reading of the tf file (--tf-u32 / AIX_REF_COMPAT=1): its files, byte for byte, without test-side massaging
+    z = np.load(os.path.join(gold, "count13", "expected.npz"))
+    tf_ref = np.zeros(4 ** 13, dtype=np.uint64)
+    tf_ref[z["synth.txt.idx"].astype(np.int64)] = z["synth.txt.cnt"]
+    tf_ref.tofile(prefix + ".ref.tf.bin")                                           # what the reference's count_kmers13 wrote for these reads
+    for how in ("flag", "env"):
+        cmd = [os.path.join(root, "bin", "compute_aindex13"), rp, pf13_path(), prefix + ".ref.tf.bin", prefix + ".ref", "4"] + (["--tf-u32"] if how == "flag" else [])
+        r = subprocess.run(cmd, env=dict(os.environ, **({"AIX_REF_COMPAT": "1"} if how == "env" else {})), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert np.array_equal(np.fromfile(prefix + ".ref.index.bin", dtype=np.uint64), g["positions"])
+        assert hashlib.sha256(open(prefix + ".ref.indices.bin", "rb").read()).digest() == bytes(g["indices_sha256"])
+        os.remove(prefix + ".ref.index.bin"); os.remove(prefix + ".ref.indices.bin")
+    os.remove(prefix + ".ref.tf.bin")
     os.symlink(pf13_path(), prefix + ".pf")
     from aindex_amd.wrapper import AindexWrapper
     w = AindexWrapper()
@@ -1481,7 +1497,19 @@ def test_positions13_reference_pin_oracle_pieces_and_mirror(gold, tmp_path, monk
     assert w.get_positions_13mer("ACGTNACGTACGT") == [] and w.get_positions_13mer("acgtacgtacgta") == [] and w.get_positions_13mer("ACGT") == []
     ind_b, pos_b = w.build_aindex(rp)
     assert np.array_equal(pos_b, opos)
+    w.load_aindex_from_prefix_13mer(prefix, ref_compat=True)                          # the reference's behaviour on request: positions never mapped
+    assert w.get_positions_13mer(reads[:13].decode()) == []
     w.close()
+    # a 13-mer table with an entry above 2^32 - 1 is refused (32-bit fill counters), never mis-filled
+    with Index.open_13(pf13_path(), None) as ixb:
+        big = tf.copy()
+        big[int(np.nonzero(tf)[0][0])] = (1 << 32) + 3
+        ixb.set_tf_13(big)
+        with pytest.raises(_lib.AixError) as ei:
+            ixb.positions_fill(reads[:5000])
+        assert ei.value.status == -6
+        ixb.set_tf_13(tf)
+        assert np.array_equal(ixb.positions_fill(reads)[1], opos)
 
 
 def test_kmer_counter_msd_path_equals_radix_path_and_oracle(monkeypatch):
@@ -1660,3 +1688,35 @@ def test_sharded_entry_points_multi_process(backend, nproc):
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = r.stdout.decode(errors="replace")
     assert r.returncode == 0 and f"DIST_GPU_OK {backend} {nproc}" in out, out[-4000:]
+
+
+def test_failing_host_batch_drains_its_streams(small23_prefix, tmp_path):
+    """a large host batch that fails in the middle (AIX_PIPE_TEST_FAIL_CHUNK: the launch of chunk 2 "fails") returns with its
+    three pipe streams drained, so the next call on the handle — which reuses the same pinned and device staging — answers correctly.
+    The hook is read once per process, hence the child process."""
+    import subprocess
+    import sys
+    code = f"""
+import sys
+sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, "tests")!r})
+import numpy as np
+import oracle_lib as O
+from aindex_amd import _lib, synth
+from aindex_amd.engine import Index
+prefix = {small23_prefix!r}
+orc = O.OracleIndex23.from_prefix(prefix)
+keys = synth.decode_kmers(orc.checker(), 23)
+q = np.ascontiguousarray(np.tile(keys, (2200, 1)))[:9_000_000].reshape(-1)          # 9 M queries = 5 chunks of 2 M
+ix = Index.open_23(prefix + ".pf", prefix + ".tf.bin", prefix + ".kmers.bin")
+try:
+    ix.tf_ascii(q)
+    print("NO_ERROR")
+except _lib.AixError as e:
+    print("FAILED_AS_ASKED", e.status)
+small = q[: 3_000_000 * 23]                                                            # 2 chunks: never reaches the failing chunk
+got = ix.tf_ascii(small)
+print("SECOND_CALL_OK" if np.array_equal(got, orc.tf_batch(small, threads=8)) else "SECOND_CALL_WRONG")
+"""
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, AIX_PIPE_TEST_FAIL_CHUNK="2"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "FAILED_AS_ASKED -5" in out and "SECOND_CALL_OK" in out, out + r.stderr.decode()[-1500:]
