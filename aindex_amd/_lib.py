@@ -44,7 +44,7 @@ class Info(C.Structure):
 class IngestStats(C.Structure):
     _fields_ = [("bytes_in", C.c_uint64), ("plain_bytes", C.c_uint64), ("parts", C.c_uint64), ("part_bytes", C.c_uint64), ("pieces", C.c_uint64),
                 ("pinned_bytes", C.c_uint64), ("device_bytes", C.c_uint64), ("workspace_bytes", C.c_uint64), ("seconds_total", C.c_double), ("seconds_read", C.c_double),
-                ("seconds_wait", C.c_double), ("seconds_h2d", C.c_double), ("seconds_compute", C.c_double), ("seconds_output", C.c_double)]
+                ("seconds_wait", C.c_double), ("seconds_h2d", C.c_double), ("seconds_normalise", C.c_double), ("seconds_compute", C.c_double), ("seconds_output", C.c_double)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -14,6 +14,7 @@
 // whole-file copy. The host-buffer twins of the ABI (aix_count13, aix_count23_fixed, aix_count_distinct, aix_positions_fill) go through
 // the same pipeline with memcpy in place of pread.
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -434,7 +435,9 @@ int PlainStream::next(const uint8_t** d, uint64_t* len) {
         head = p.d - Ingest::HDR;
     } else {
         head = d_plain;
+        const double tn = now_s();
         const hipError_t e = normalise_device_part(p.d, p.len, format, fasta_mode, d_plain + Ingest::HDR, &plain_len, &norm_state, p.last ? 1 : 0, stream);
+        seconds_normalise += now_s() - tn;
         if (e != hipSuccess) { set_last_error(std::string("normalise part: ") + hipGetErrorString(e)); return AIX_ERR_HIP; }
         const int r = in.release(stream);                       // the raw bytes have been read (the normaliser synchronised the stream)
         if (r) return r;
@@ -468,6 +471,7 @@ void PlainStream::fill_stats(aix_ingest_stats_t* st) const {
     st->seconds_read = in.seconds_read;
     st->seconds_wait = in.seconds_wait;
     st->seconds_h2d = in.seconds_h2d;
+    st->seconds_normalise = seconds_normalise;
 }
 
 }  // namespace aix
@@ -516,27 +520,65 @@ static int count23_source(aix_index_t* h, const ByteSource& src, int format, int
     return st;
 }
 
-// The output file of a tool run is created and its pages allocated WHILE the input is being counted (tmpfs / page cache allocate and zero
-// 512 MiB at a few GB/s; done afterwards that is a third of the whole call): a background thread, joined before the result is written.
+// The output file of a tool run is created, mapped and its pages allocated WHILE the input is being counted (tmpfs / the page cache allocate
+// and zero 512 MiB at a few GB/s, and write() calls on one file are serialised by the inode lock: written afterwards with pwrite the file cost
+// a third of the whole call). A background thread faults the mapping in; the result is then copied into it by the host threads.
 struct OutputFile {
     int fd = -1;
+    uint8_t* map = nullptr;
+    uint64_t bytes = 0;
     std::thread th;
-    int open_and_reserve(const char* path, uint64_t bytes) {
-        fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    int open_and_reserve(const char* path, uint64_t n) {
+        fd = ::open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);
         if (fd < 0) return AIX_ERR_IO;
+        bytes = n;
+        if (n && ftruncate(fd, (off_t)n) != 0) { ::close(fd); fd = -1; return AIX_ERR_IO; }
+        if (n) {
+            void* m = mmap(nullptr, n, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            if (m != MAP_FAILED) map = (uint8_t*)m;               // no mapping (an odd file system): the pwrite path below
+        }
+        uint8_t* mp = map;
         const int f = fd;
-        th = std::thread([f, bytes] { if (bytes && posix_fallocate(f, 0, (off_t)bytes) != 0) (void)ftruncate(f, (off_t)bytes); });
+        th = std::thread([mp, f, n] {
+            if (mp) {
+#ifdef MADV_POPULATE_WRITE
+                if (madvise(mp, n, MADV_POPULATE_WRITE) == 0) return;
+#endif
+                for (uint64_t o = 0; o < n; o += 4096) ((volatile uint8_t*)mp)[o] = 0;
+            } else if (n) {
+                (void)posix_fallocate(f, 0, (off_t)n);
+            }
+        });
         return AIX_OK;
     }
     void ready() { if (th.joinable()) th.join(); }
+    // file[lo, lo + m) = from[0, m), host threads side by side
+    int put(uint64_t lo, const char* from, uint64_t m) {
+        if (map) {
+            host_workers().sliced(m, [&](uint64_t a, uint64_t b) { memcpy(map + lo + a, from + a, b - a); });
+            return AIX_OK;
+        }
+        std::atomic<int> bad{0};
+        const int f = fd;
+        host_workers().sliced(m, [&](uint64_t a, uint64_t b) {
+            while (a < b) {
+                const ssize_t r = pwrite(f, from + a, b - a, (off_t)(lo + a));
+                if (r <= 0) { bad = 1; return; }
+                a += (uint64_t)r;
+            }
+        });
+        return bad ? AIX_ERR_IO : AIX_OK;
+    }
     int close_file() {
         ready();
         int st = AIX_OK;
+        if (map && munmap(map, bytes) != 0) st = AIX_ERR_IO;
+        map = nullptr;
         if (fd >= 0 && ::close(fd) != 0) st = AIX_ERR_IO;
         fd = -1;
         return st;
     }
-    ~OutputFile() { ready(); if (fd >= 0) ::close(fd); }
+    ~OutputFile() { ready(); if (map) munmap(map, bytes); if (fd >= 0) ::close(fd); }
 };
 
 // The result of a counting call leaves in 32 MiB slices through two pooled pinned blocks: slice i is written to the file (pwrite, host
@@ -574,33 +616,15 @@ static int download(void* host_dst, OutputFile* of, const void* d_src, uint64_t 
             if (i + 1 < nsl) { st = issue(i + 1); if (st) break; }
             const uint64_t lo = i * slice, m = std::min(slice, bytes - lo);
             const char* from = (const char*)pin[i & 1];
-            std::atomic<int> bad{0};
-            const int fd = of ? of->fd : -1;
             char* mem = (host_dst && !dst_pinned) ? (char*)host_dst + lo : nullptr;
-            host_workers().sliced(m, [&](uint64_t a, uint64_t b) {
-                if (mem) memcpy(mem + a, from + a, b - a);
-                while (fd >= 0 && a < b) {
-                    const ssize_t r = pwrite(fd, from + a, b - a, (off_t)(lo + a));
-                    if (r <= 0) { bad = 1; return; }
-                    a += (uint64_t)r;
-                }
-            });
-            if (bad) st = AIX_ERR_IO;
+            if (mem) host_workers().sliced(m, [&](uint64_t a, uint64_t b) { memcpy(mem + a, from + a, b - a); });
+            if (of) st = of->put(lo, from, m);
         }
         (void)hipStreamSynchronize(s);
         for (int b = 0; b < 2; ++b) { pinned_pool().put(pin[b], slice); if (ev[b]) (void)hipEventDestroy(ev[b]); }
     } else if (!st && of && host_dst && bytes) {                 // pinned destination and a file: the file is written from the caller's copy
         of->ready();
-        std::atomic<int> bad{0};
-        const int fd = of->fd;
-        host_workers().sliced(bytes, [&](uint64_t a, uint64_t b) {
-            while (a < b) {
-                const ssize_t r = pwrite(fd, (const char*)host_dst + a, b - a, (off_t)a);
-                if (r <= 0) { bad = 1; return; }
-                a += (uint64_t)r;
-            }
-        });
-        if (bad) st = AIX_ERR_IO;
+        st = of->put(0, (const char*)host_dst, bytes);
     }
     if (of) { const int c = of->close_file(); if (!st) st = c; }
     if (st == AIX_ERR_HIP) set_last_error("result download failed");
@@ -713,7 +737,7 @@ __global__ void k_move_tail(uint8_t* __restrict__ buf, uint64_t fill, uint32_t k
 static int distinct_source(const ByteSource& src, int format, int k, int canon_mode, uint64_t min_count, int device, hipStream_t s, uint64_t** dk, uint64_t** dc,
                            uint64_t* n_out, aix_ingest_stats_t* stats) {
     *dk = nullptr; *dc = nullptr; *n_out = 0;
-    uint64_t piece_win = 1ull << 31;
+    uint64_t piece_win = 1ull << 30;                          // as distinct_from_plain (aix_merge.hip)
     if (const char* e = getenv("AIX_DISTINCT_PIECE")) { const uint64_t v = strtoull(e, nullptr, 10); if (v >= 1 && v <= (1ull << 31)) piece_win = v; }   // test hook: merges at small sizes
     PlainStream ps(src, format, 1, k, device, s);
     int st = ps.start();

@@ -94,6 +94,7 @@ private:
     uint8_t* d_carry = nullptr;
     uint8_t* d_plain = nullptr;
     uint64_t plain_dev_bytes = 0, plain_total = 0;
+    double seconds_normalise = 0;
     uint32_t norm_state = 0xFFFFFFFFu;                       // AIX_NORM_START
     uint8_t* cur_head = nullptr;
     uint64_t cur_plain = 0;

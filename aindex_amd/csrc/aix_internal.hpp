@@ -108,9 +108,35 @@ hipError_t distinct_from_codes(uint64_t* d_codes, uint64_t nwin, int k, uint64_t
 // the same without a full-width sort (aix_k1.hip): MSD partition in two levels + per-bucket LDS hash / sort. d_codes is clobbered.
 // *fell_back: a bucket held too many distinct remainders; nothing was produced and the caller takes the radix-sort path.
 bool k1_msd_eligible(uint64_t nwin, int k);
+// The two big temporaries of a K1 piece (8 B per window of code / remainder staging, ~8 B per window of partition chunks: 16 + 17 GiB for a
+// 2^31-window piece), kept by whoever counts piece after piece: a hipMalloc / hipFree pair of that size costs ~0.2 s, more than the kernels
+// of the piece (measured: 60 M reads in 5 pieces took 2.5 s of wall clock around 0.16 s of kernels before the blocks were kept).
+struct K1Scratch {
+    void* codes = nullptr;
+    size_t codes_bytes = 0;
+    void* work = nullptr;
+    size_t work_bytes = 0;
+    hipStream_t s = nullptr;
+    K1Scratch() = default;
+    K1Scratch(const K1Scratch&) = delete;
+    K1Scratch& operator=(const K1Scratch&) = delete;
+    hipError_t need(void** p, size_t* have, size_t bytes) {
+        if (bytes <= *have) return hipSuccess;
+        if (*p) { (void)hipStreamSynchronize(s); pool_free(*p); *p = nullptr; *have = 0; }
+        const hipError_t e = pool_alloc(p, bytes);              // from the block cache: a process that counts buffer after buffer finds them there again
+        if (e == hipSuccess) *have = bytes;
+        return e;
+    }
+    ~K1Scratch() {
+        if (codes || work) (void)hipStreamSynchronize(s);
+        if (codes) pool_free(codes);
+        if (work) pool_free(work);
+    }
+};
 hipError_t distinct_from_codes_msd(uint64_t* d_codes, uint64_t nwin, int k, uint64_t** d_keys_out, uint32_t** d_counts_out, uint64_t* n_out, bool* fell_back,
                                    hipStream_t s, const uint8_t* d_plain = nullptr /* encode inside level 1 */, uint64_t plen = 0, int canon_mode = 0,
-                                   uint64_t** d_counts64_out = nullptr /* non-null: the counts come back as u64 here, *d_counts_out stays null */);
+                                   uint64_t** d_counts64_out = nullptr /* non-null: the counts come back as u64 here, *d_counts_out stays null */,
+                                   K1Scratch* scratch = nullptr /* non-null: the partition workspace lives there, kept for the next piece */);
 hipError_t distinct_from_plain(const uint8_t* d_plain, uint64_t plen, int k, int canon_mode, uint64_t min_count, uint64_t piece, uint64_t** d_keys_out,
                                uint64_t** d_counts_out, uint64_t* n_out, hipStream_t s);
 hipError_t merge_counts(const uint64_t* d_keys, const uint64_t* d_counts, uint64_t n, uint64_t min_count, uint64_t** d_keys_out, uint64_t** d_counts_out,
@@ -147,6 +173,7 @@ public:
 private:
     int k, canon_mode;
     hipStream_t s;
+    K1Scratch scratch;
     uint64_t* acc_k = nullptr;
     uint64_t* acc_c = nullptr;
     uint64_t acc_n = 0;

@@ -276,7 +276,7 @@ bool k1_msd_eligible(uint64_t nwin, int k) {
 // d_plain != nullptr: the windows are encoded inside level 1 (no code array is read; d_codes is then only the 8 B-per-window
 // scratch the later stages re-use). plen = bytes of the PLAIN buffer.
 hipError_t distinct_from_codes_msd(uint64_t* d_codes, uint64_t nwin, int k, uint64_t** d_keys_out, uint32_t** d_counts_out, uint64_t* n_out, bool* fell_back,
-                                   hipStream_t s, const uint8_t* d_plain, uint64_t plen, int canon_mode, uint64_t** d_counts64_out) {
+                                   hipStream_t s, const uint8_t* d_plain, uint64_t plen, int canon_mode, uint64_t** d_counts64_out, K1Scratch* scratch) {
     *d_keys_out = nullptr; *d_counts_out = nullptr; *n_out = 0; *fell_back = false;
     if (d_counts64_out) *d_counts64_out = nullptr;
     const uint32_t B = 2u * (uint32_t)k, s1 = B - K1_PBITS;
@@ -305,8 +305,9 @@ hipError_t distinct_from_codes_msd(uint64_t* d_codes, uint64_t nwin, int k, uint
                    o_dm = o_bbase + up256(4ull * (nbuckets + 1)), o_dmo = o_dm + up256(4ull * (nbuckets + 1)), o_parts = o_dmo + up256(4ull * (nbuckets + 1)),
                    total = o_parts + 8ull * cap * K1_CH;
     uint8_t* w = nullptr;
-    hipError_t e = pool_alloc((void**)&w, total);
+    hipError_t e = scratch ? scratch->need(&scratch->work, &scratch->work_bytes, total) : pool_alloc((void**)&w, total);
     if (e != hipSuccess) return e;
+    if (scratch) w = (uint8_t*)scratch->work;
     uint32_t* err = (uint32_t*)(w + o_flags);
     uint32_t* overflow = err + 1;
     uint16_t* dir_part = (uint16_t*)(w + o_dirp);
@@ -375,7 +376,7 @@ hipError_t distinct_from_codes_msd(uint64_t* d_codes, uint64_t nwin, int k, uint
         if (e == hipSuccess) e = hipStreamSynchronize(s);
     } while (false);
     { const hipError_t es = hipStreamSynchronize(s); if (e == hipSuccess) e = es; }
-    pool_free(w);
+    if (!scratch) pool_free(w);
     if (e != hipSuccess || *fell_back) {
         if (keys) pool_free(keys);
         if (counts) pool_free(counts);

@@ -201,7 +201,7 @@ static hipError_t filter_min_count(uint64_t** k, uint64_t** c, uint64_t* n, uint
 // DistinctAcc: the distinct set of everything added so far (K1 for buffers / files of any length). A piece = every k-window of one
 // PLAIN buffer of at most 2^31 windows; its distinct set (aix_k1.hip, or the radix-sort path) is merged into the accumulated one.
 // ---------------------------------------------------------------------------------------------
-DistinctAcc::DistinctAcc(int kk, int canon, hipStream_t st) : k(kk), canon_mode(canon), s(st) {}
+DistinctAcc::DistinctAcc(int kk, int canon, hipStream_t st) : k(kk), canon_mode(canon), s(st) { scratch.s = st; }
 DistinctAcc::~DistinctAcc() {
     if (acc_k || acc_c) (void)hipStreamSynchronize(s);
     if (acc_k) pool_free(acc_k);
@@ -213,15 +213,17 @@ hipError_t DistinctAcc::add_plain(const uint8_t* d_plain, uint64_t plen) {
     const uint64_t nwin = plen - k + 1;
     if (nwin > (1ull << 31)) return hipErrorInvalidValue;
     ++pieces;
-    DevArr codes(s);
-    hipError_t e = codes.alloc(8 * nwin);
+    // the 8 B-per-window staging and the partition workspace stay with the accumulator from piece to piece (K1Scratch)
+    struct { void* p; } codes{nullptr};
+    hipError_t e = scratch.need(&scratch.codes, &scratch.codes_bytes, 8 * nwin);
+    codes.p = scratch.codes;
     uint64_t* pk = nullptr; uint32_t* pc = nullptr; uint64_t pm = 0;
     uint64_t* pc64 = nullptr;                                             // the MSD path hands its counts over as u64 (no widening pass)
     bool sorted_path = !k1_msd_eligible(nwin, k);
     if (e == hipSuccess && sorted_path) e = launch_window_codes(d_plain, plen, k, canon_mode, (uint64_t*)codes.p, s);
     if (e == hipSuccess && !sorted_path) {                                // MSD partition + per-bucket LDS hash / sort (aix_k1.hip); windows encoded inside level 1
         bool fell_back = false;
-        e = distinct_from_codes_msd((uint64_t*)codes.p, nwin, k, &pk, &pc, &pm, &fell_back, s, d_plain, plen, canon_mode, &pc64);
+        e = distinct_from_codes_msd((uint64_t*)codes.p, nwin, k, &pk, &pc, &pm, &fell_back, s, d_plain, plen, canon_mode, &pc64, &scratch);
         if (e == hipSuccess && fell_back) {                               // a bucket too rich for LDS: the codes were used as staging, make them again
             sorted_path = true;
             e = launch_window_codes(d_plain, plen, k, canon_mode, (uint64_t*)codes.p, s);
@@ -237,7 +239,6 @@ hipError_t DistinctAcc::add_plain(const uint8_t* d_plain, uint64_t plen) {
         e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
-    codes.drop();
     if (acc_n == 0) {                                                     // the first non-empty piece: sorted, distinct, u64 counts — taken as it is
         (void)hipStreamSynchronize(s);
         acc_k = (uint64_t*)hold_k.release(); acc_c = (uint64_t*)hold_c64.release(); acc_n = pm;
@@ -267,7 +268,10 @@ hipError_t distinct_from_plain(const uint8_t* d_plain, uint64_t plen, int k, int
     *d_keys_out = nullptr; *d_counts_out = nullptr; *n_out = 0;
     if (plen < (uint64_t)k) return hipSuccess;
     const uint64_t nwin_all = plen - k + 1;
-    if (piece == 0 || piece > (1ull << 31)) piece = 1ull << 31;              // 32-bit window indices inside a piece
+    // 32-bit window indices inside a piece allow 2^31 windows; the default is 2^30: the two big temporaries of a piece are then 8 and 8.5 GiB
+    // and stay in the block cache between calls (16 + 17 GiB did not: every call paid ~0.75 s of hipMalloc / hipFree), at the price of one more
+    // 2.4 ms merge per 2^30 windows
+    if (piece == 0 || piece > (1ull << 31)) piece = 1ull << 30;
     DistinctAcc acc(k, canon_mode, s);
     for (uint64_t w0 = 0; w0 < nwin_all; w0 += piece) {                      // a window belongs to the piece that holds its first byte
         const uint64_t nwin = std::min(piece, nwin_all - w0);

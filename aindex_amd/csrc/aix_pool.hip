@@ -2,7 +2,7 @@
 // hipMalloc of a multi-GB block costs ~20 ms on this stack, and the K1 / A2 / I1 entry points used to make 5-15 of
 // them per call (0.3 s of allocation around 0.04 s of kernels). Blocks are cached per device and handed out again
 // (smallest cached block that fits, at most 2x oversize). A block is only released by code that has synchronised the
-// stream it was used on, so a cached block never has work pending. AIX_SCRATCH_CACHE_GB (default 16) bounds what is
+// stream it was used on, so a cached block never has work pending. AIX_SCRATCH_CACHE_GB (default 40) bounds what is
 // kept; aix_scratch_trim() and aix_index_close() return everything to the driver (memory parked here is invisible to other
 // allocators in the process, e.g. torch's).
 #include <cstdlib>
@@ -23,7 +23,7 @@ size_t g_cached = 0;
 size_t cache_limit() {
     static const size_t lim = [] {
         const char* e = getenv("AIX_SCRATCH_CACHE_GB");
-        const double gb = e ? atof(e) : 16.0;
+        const double gb = e ? atof(e) : 40.0;
         return (size_t)(gb < 0 ? 0 : gb * (double)(1ull << 30));
     }();
     return lim;

@@ -73,7 +73,7 @@ const char* aix_version(void);
 const char* aix_strerror(int status);
 int aix_device_count(int* count);
 /* Calls that need multi-GB temporaries (K1, A1/A2, I1, host-buffer staging) take them from a per-device cache of device
- * blocks (a hipMalloc of that size costs ~20 ms). AIX_SCRATCH_CACHE_GB (default 16) bounds the cache; this and
+ * blocks (a hipMalloc of that size costs ~20 ms). AIX_SCRATCH_CACHE_GB (default 40) bounds the cache; this and
  * aix_index_close() return it to the driver. */
 void aix_scratch_trim(void);                     /* AIX_ERR_HIP if the runtime is unusable  */
 
@@ -243,7 +243,8 @@ typedef struct {
     double seconds_read;       /* file / page cache -> pinned staging (sum over parts, overlapped)         */
     double seconds_wait;       /* the consumer waited for a part to arrive                                 */
     double seconds_h2d;        /* the parts on the link (HIP events around every copy, summed; the last three parts are not counted) */
-    double seconds_compute;    /* normalise + count as seen by the host (includes the waits inside)        */
+    double seconds_normalise;  /* FASTA / FASTQ parts: the transducer pass (waits for the part to arrive included) */
+    double seconds_compute;    /* counting as seen by the host (includes the waits inside)                 */
     double seconds_output;     /* result download + file write                                             */
 } aix_ingest_stats_t;
 /* Pin the staging blocks of a streaming call in the background and return at once (optional): a process that streams ONE file — a tool run —
@@ -314,11 +315,11 @@ int aix_positions_fill_shard_dev(aix_index_t* h, const char* d_reads, uint64_t l
  * (canonical k-mer code, count) with count >= min_count, sorted by code ascending (the reference sorts by count with
  * unspecified tie order; parity is on the set). *keys_out / *counts_out are malloc'd (aix_free). format as for the
  * counters (FASTA records follow count_kmers.cpp:250-295). 1 <= k <= 31; any length (buffers of more
- * than 2^31 windows are counted piece by piece and the sorted distinct sets MERGED, never re-sorted — count_kmers.cpp:334-341 merges its
+ * than 2^30 windows are counted piece by piece and the sorted distinct sets MERGED, never re-sorted — count_kmers.cpp:334-341 merges its
  * per-thread maps once; counts and sizes are 64-bit). */
 int aix_count_distinct(const char* buf, uint64_t len, int format, int k, int canon_mode, uint64_t min_count, int device,
                        uint64_t** keys_out, uint64_t** counts_out, uint64_t* n_out);
-/* the same from a file, streamed (see aix_count13_file): pieces of 2^31 windows are counted as the parts arrive, their sorted sets merged */
+/* the same from a file, streamed (see aix_count13_file): pieces of 2^30 windows are counted as the parts arrive, their sorted sets merged */
 int aix_count_distinct_file(const char* path, int format, int k, int canon_mode, uint64_t min_count, int device, uint64_t** keys_out,
                             uint64_t** counts_out, uint64_t* n_out, aix_ingest_stats_t* stats);
 /* device-resident twin: d_plain is a PLAIN buffer in HBM; the (key, count) arrays stay in HBM inside *out until the caller
