@@ -848,6 +848,13 @@ extern "C" int aix_count23_fixed_dev(aix_index_t* h, const char* d_plain, uint64
     // the slot-stream probe of the counter runs best with two lanes per bucket line (38.7-40.4 against 42.5-42.7 ms per 10 M reads with
     // eight, same box): nothing but the 4-byte slot leaves the kernel, so fewer, wider reads per probe win; lookups keep eight
     const IndexDev dc = h->dev_slots();
+    // probe kernel of the slot stream: one window per lane (k_probe23_slots) or a run of 16 / 32 windows per lane (k_run23_slots: the bytes are
+    // encoded once per run). AIX_COUNT23_RUN=0 / 16 / 32 (A/B switch).
+    int run_w = 0;
+    if (const char* e = getenv("AIX_COUNT23_RUN")) { const int v = atoi(e); if (v == 16 || v == 32) run_w = v; }
+    auto probe = [&](const uint8_t* p, uint64_t n, uint32_t* out, hipStream_t st) {
+        return (run_w && dc.bk) ? launch_run23_slots(dc, p, n, canon_mode, out, run_w, st) : launch_probe23_slots(dc, p, n, canon_mode, out, st);
+    };
     uint64_t ip = 0;
     for (uint64_t first = 0; first < nwin; first += pw, ++ip) {
         const uint64_t w = std::min(pw, nwin - first);
@@ -858,11 +865,11 @@ extern "C" int aix_count23_fixed_dev(aix_index_t* h, const char* d_plain, uint64
         } else if (overlap) {
             const int b = (int)(ip & 1);
             if (ip >= 2) HIPCHK(hipStreamWaitEvent(h->probe_stream, h->hist_ev[b], 0));      // piece ip - 2 has been read out of this buffer
-            HIPCHK(launch_probe23_slots(dc, (const uint8_t*)d_plain + first, w + 22, canon_mode, slots, h->probe_stream));
+            HIPCHK(probe((const uint8_t*)d_plain + first, w + 22, slots, h->probe_stream));
             HIPCHK(hipEventRecord(h->probe_ev[b], h->probe_stream));
             HIPCHK(hipStreamWaitEvent(s, h->probe_ev[b], 0));
         } else {
-            HIPCHK(launch_probe23_slots(dc, (const uint8_t*)d_plain + first, w + 22, canon_mode, slots, s));
+            HIPCHK(probe((const uint8_t*)d_plain + first, w + 22, slots, s));
         }
         uint32_t passes = 0;
         HIPCHK(launch_histogram_slots(slots, w, h->work13, d_tf_out, h->n, s, range_bits, &passes));

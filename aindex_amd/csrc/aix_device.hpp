@@ -478,6 +478,68 @@ __device__ __forceinline__ BkRes line_probe_wave(const BkEntry* __restrict__ tab
     return res;
 }
 
+// The same probe in two halves, for kernels that keep MORE THAN ONE probe per lane in flight (k_run23_slots: the line of window j + 1 is
+// requested before window j is compared, so a wave has twice as many lines outstanding): line_issue sends the loads, line_resolve compares.
+template <int LPP>
+struct LineRegs {
+    uint4 e[LPP][8 / LPP];
+    uint32_t bsrc[LPP];
+};
+template <int LPP>
+__device__ __forceinline__ void line_issue(const BkEntry* __restrict__ tab, uint32_t my_line, LineRegs<LPP>& L) {
+    constexpr int EPL = 8 / LPP;
+    const uint32_t lane = __lane_id();
+    const uint32_t j = lane & (LPP - 1), gbase = lane & ~(uint32_t)(LPP - 1);
+#pragma unroll
+    for (int r = 0; r < LPP; ++r) {
+        L.bsrc[r] = LPP == 1 ? my_line : bperm(gbase + r, my_line);
+#pragma unroll
+        for (int t = 0; t < EPL; ++t) L.e[r][t] = make_uint4(0xFFFFFFFFu, AIX_BK_EMPTY_HI, 0u, 0u);
+        if (__ballot(L.bsrc[r] != AIX_BK_NONE) != 0ull) {
+            const uint4* p = (const uint4*)(tab + (uint64_t)(L.bsrc[r] != AIX_BK_NONE ? L.bsrc[r] : 0u) * 8 + j * EPL);
+#pragma unroll
+            for (int t = 0; t < EPL; ++t) L.e[r][t] = p[t];
+        }
+    }
+}
+template <int LPP>
+__device__ __forceinline__ BkRes line_resolve(const LineRegs<LPP>& L, uint64_t code) {
+    constexpr int EPL = 8 / LPP;
+    const uint32_t lane = __lane_id();
+    const uint32_t j = lane & (LPP - 1), gbase = lane & ~(uint32_t)(LPP - 1);
+    const uint32_t my_lo = (uint32_t)code, my_hi = (uint32_t)(code >> 32);
+    BkRes res{0u, 0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int r = 0; r < LPP; ++r) {
+        const uint32_t c_lo = LPP == 1 ? my_lo : bperm(gbase + r, my_lo);
+        const uint32_t c_hi = LPP == 1 ? my_hi : bperm(gbase + r, my_hi);
+        const bool live = L.bsrc[r] != AIX_BK_NONE;
+        uint32_t h_tf = 0, h_slot = 0;
+        bool m = false, hole = false;
+#pragma unroll
+        for (int t = 0; t < EPL; ++t) {
+            const bool mm = live && L.e[r][t].x == c_lo && (L.e[r][t].y & AIX_BK_HI_MASK) == c_hi;
+            if (mm) { m = true; h_tf = L.e[r][t].z; h_slot = L.e[r][t].w; }
+            hole = hole || (L.e[r][t].y & AIX_BK_HI_MASK) == AIX_BK_EMPTY_HI;
+        }
+        const bool ov = live && j == (uint32_t)(LPP - 1) && (L.e[r][EPL - 1].y & AIX_BK_OVERFLOW);
+        if (LPP == 1) {
+            res.found = m; res.tf = h_tf; res.slot = h_slot; res.overflow = ov; res.full = live && !hole;
+        } else {
+            const uint64_t bal = __ballot(m), balov = __ballot(ov), balhole = __ballot(live && hole);
+            const uint32_t grp = (uint32_t)(bal >> gbase) & ((1u << LPP) - 1u);
+            const uint32_t ml = gbase + (grp ? (uint32_t)__builtin_ctz(grp) : 0u);
+            const uint32_t v_tf = bperm(ml, h_tf), v_slot = bperm(ml, h_slot);
+            if (j == (uint32_t)r) {
+                res.found = grp != 0u; res.tf = v_tf; res.slot = v_slot;
+                res.overflow = (uint32_t)(balov >> (gbase + LPP - 1)) & 1u;
+                res.full = live && (((uint32_t)(balhole >> gbase) & ((1u << LPP) - 1u)) == 0u);
+            }
+        }
+    }
+    return res;
+}
+
 // verification table keyed by the k-mer's own hash: bucket = mulhi64(a, nb)
 template <int LPP>
 __device__ __forceinline__ BkRes bucket_probe_wave(const BkEntry* __restrict__ bk, uint32_t nb, bool want, uint64_t a, uint64_t code) {

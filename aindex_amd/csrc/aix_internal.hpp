@@ -81,6 +81,8 @@ hipError_t launch_histogram_slots(const uint32_t* d_slots, uint64_t nslots, void
 hipError_t launch_stream23_slots(const IndexDev& ix, const uint8_t* buf, uint64_t len, int canon_mode, uint32_t* slots /* [len - 22] */,
                                  uint32_t* flag /* zeroed word: set when a window stayed undecided */, hipStream_t s);
 hipError_t launch_probe23_slots(const IndexDev& ix, const uint8_t* buf, uint64_t len, int canon_mode, uint32_t* slots /* [len - 22] */, hipStream_t s);
+// the same slot stream with a run of w (16 / 32) consecutive windows per lane (aix_stream23.hip: the bytes are encoded once per run); needs ix.bk
+hipError_t launch_run23_slots(const IndexDev& ix, const uint8_t* buf, uint64_t len, int canon_mode, uint32_t* slots, int w, hipStream_t s);
 hipError_t launch_scatter13_to_mphf(const uint32_t* perm, const unsigned long long* table_code, uint64_t* out_mphf, int add, hipStream_t s);
 hipError_t launch_perm13_check(const uint32_t* perm, uint32_t* bits /* 4^13 / 32 zeroed words */, uint32_t* bad /* zeroed */, hipStream_t s);
 hipError_t launch_count23_fixed(const IndexDev& ix, const uint8_t* buf, uint64_t len, int canon_mode, uint32_t* tf_out, hipStream_t s);

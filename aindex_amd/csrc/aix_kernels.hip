@@ -850,7 +850,11 @@ __global__ void __launch_bounds__(kBlock) k_gather(const uint8_t* __restrict__ t
         for (int u = 0; u < UNROLL; ++u) idx[u] = ((sm64(seed, i + u) >> 32) * n_elems) >> 32;
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
-            if (ELEM == 16) {
+            if (ELEM >= 32) {                                   // the whole element: ELEM / 16 loads of 16 bytes (a 64-byte half line, a 128-byte line)
+                const uint4* p = (const uint4*)(table + idx[u] * (uint64_t)ELEM);
+#pragma unroll
+                for (int t = 0; t < ELEM / 16; ++t) { const uint4 v = p[t]; acc += (uint64_t)v.x ^ v.w; }
+            } else if (ELEM == 16) {
                 const BvRec r = ((const BvRec*)table)[idx[u]];
                 acc += r.fp ^ r.prefix;
             } else if (ELEM == 8) {
@@ -1017,7 +1021,7 @@ hipError_t launch_gather(const uint8_t* table, uint64_t n_elems, int elem, int u
     if (n_access == 0) return hipSuccess;
     const uint64_t work = (n_access + unroll - 1) / unroll;
 #define G(E, U) if (elem == E && unroll == U) AIX_LAUNCH((k_gather<E, U>), work, s, table, n_elems, n_access, seed, sink)
-    G(16, 1); G(16, 4); G(8, 1); G(8, 4); G(4, 1); G(4, 4);
+    G(16, 1); G(16, 4); G(8, 1); G(8, 4); G(4, 1); G(4, 4); G(32, 1); G(64, 1); G(128, 1);
 #undef G
     return hipErrorInvalidValue;
 }

@@ -218,6 +218,161 @@ __global__ void __launch_bounds__(S23_TB) k_stream23_slots(const IndexDev ix, co
     if (__ballot(und) != 0ull && lane == 0) *any_undecided = 1u;                      // without the verification table: k_fix23 has something to do
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_run23_slots: the hash-keyed verification table (one 128-byte line per window, as k_probe23_slots) probed by lanes that own a RUN of
+// W consecutive window starts. Static VALU budget of k_probe23_slots per window (ISA listing, profiles/r03/probe23_valu_budget.txt):
+// unaligned 23-byte load 22, upper-case + U->T + 4-byte SWAR encode 139, reverse complement + strand pick 16, ASCII of the canonical
+// strand 45, Jenkins 74, bucket choice + wave-cooperative line read + compare 87 — the encode is the largest item and consecutive windows
+// share 22 of their 23 bytes. Here the lane's W + 22 bytes are encoded ONCE (encode_run23: ~25 operations per 4 bytes, i.e. ~11-16 per
+// window), a window's code is a shift of the 2-bit stream (~8), and the rest is unchanged: ~260 against ~383 per window, the same single
+// line per window, the same slot stream out (through LDS, so that the stores stay coalesced). Windows behind an overflowed bucket are
+// marked undecided and settled in the epilogue (bucket again, then the MPHF), exactly as in k_stream23_slots.
+// ---------------------------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ Run23 encode_run_w(const uint8_t* __restrict__ buf, uint64_t len, uint64_t S) {
+    static_assert(W == 16 || W == 32, "window starts per lane");
+    constexpr int ND = (W + 22 + 3) / 4;                          // dwords of the lane's bytes: 10 (W = 16) / 14 (W = 32)
+    Run23 r{0, 0, 0};
+    if (S >= len) return r;
+    const uint64_t limit = len - S;
+    uint32_t e[ND];
+    {
+        const uint32_t o = (uint32_t)((uintptr_t)(buf + S) & 3);
+        const uint32_t* q = (const uint32_t*)(buf + S - o);
+        const int64_t first = (int64_t)S - o, end = (int64_t)len;
+        uint32_t d[ND + 1];
+#pragma unroll
+        for (int k = 0; k <= ND; ++k) d[k] = (first + 4 * k < end) ? q[k] : 0x0A0A0A0Au;
+        const uint32_t sh = o * 8;
+#pragma unroll
+        for (int k = 0; k < ND; ++k) e[k] = __funnelshift_r(d[k], d[k + 1], sh);
+    }
+    uint32_t w[4] = {0, 0, 0, 0};
+    uint64_t vmask = 0;
+#pragma unroll
+    for (int k = 0; k < ND; ++k) {
+        uint32_t x = e[k] & 0xDFDFDFDFu;
+        {
+            const uint32_t z = x ^ 0x55555555u;
+            const uint32_t nz = (((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z) & 0x80808080u;
+            x ^= (~nz & 0x80808080u) >> 7;
+        }
+        const uint32_t v = ((x >> 1) ^ (x >> 2)) & 0x03030303u;
+        const uint32_t diff = x ^ lut4(v, AIX_LUT_ACGT);
+        const uint32_t z = ~(((diff & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | diff | 0x7F7F7F7Fu);
+        const uint32_t f = z >> 7;
+        const uint32_t nib = (f | (f >> 7) | (f >> 14) | (f >> 21)) & 0xFu;
+        const uint32_t q = ((v << 6) & 0xC0u) | ((v >> 4) & 0x30u) | ((v >> 14) & 0x0Cu) | (v >> 24);
+        w[k >> 2] |= q << (24 - 8 * (k & 3));
+        vmask |= (uint64_t)nib << (4 * k);
+    }
+    if (limit < 64) vmask &= (1ull << limit) - 1;
+    r.hi = ((uint64_t)w[0] << 32) | w[1];
+    r.lo = ((uint64_t)w[2] << 32) | w[3];
+    r.vmask = vmask;
+    return r;
+}
+
+template <int W, int LPP>
+__global__ void __launch_bounds__(S23_TB) k_run23_slots(const IndexDev ix, const uint8_t* __restrict__ buf, uint64_t len, uint64_t nwin, int canon_mode,
+                                                       uint32_t* __restrict__ slots) {
+    __shared__ uint32_t tr[S23_TB / 64][64 * (W + 1)];           // per wave: lane-major results, transposed into coalesced stores
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t wave_first = ((uint64_t)blockIdx.x * S23_TB + (threadIdx.x & ~63u)) * W;
+    if (wave_first >= nwin) return;
+    const uint64_t S = wave_first + (uint64_t)lane * W;
+    const Run23 run = encode_run_w<W>(buf, len, S);
+    const uint64_t m = run.vmask, m2 = m & (m >> 1), m4 = m2 & (m2 >> 2), m8 = m4 & (m4 >> 4), m16 = m8 & (m8 >> 8);
+    const uint32_t valid = (uint32_t)(m16 & (m4 >> 16) & (m2 >> 20) & (m >> 22));   // window j holds a 23-mer iff 23 consecutive mask bits are set
+    uint32_t* mine = &tr[wave][lane * (W + 1)];
+    const uint64_t seed = ix.m.seed;
+    // canonical key of window j and the line it wants (AIX_BK_NONE: not a 23-mer)
+    auto key_of = [&](int j, uint64_t& key) -> uint32_t {
+        const uint32_t sh = 82u - 2u * (uint32_t)j;                                  // 46 bits at base j of the stream: bits [82 - 2 j, 128 - 2 j) of hi:lo
+        const uint64_t code = (sh >= 64u ? run.hi >> (sh - 64u) : (run.hi << (64u - sh)) | (run.lo >> sh)) & ((1ULL << 46) - 1);
+        key = code;
+        if (canon_mode == 2) { const uint64_t x = revcomp(code, 23); key = code < x ? code : x; }
+        else if (canon_mode == 1) { const uint64_t x = revcomp_refx86(code, 23); key = code < x ? code : x; }
+        uint64_t s0, s1, s2, a, b, c;
+        ascii23_of_rc(revcomp(key, 23), s0, s1, s2);
+        jenkins23(s0, s1, s2, seed, a, b, c);
+        return ((valid >> j) & 1u) ? bucket_of(a, ix.nb) : AIX_BK_NONE;
+    };
+    // two probes per lane in flight: the line of window j + 1 is requested before window j is compared
+    uint64_t ka, kb;
+    uint32_t la, lb;
+    constexpr int L_ = LPP;
+    auto settle = [&](int j, const LineRegs<L_>& L, uint64_t key, uint32_t line) {
+        const BkRes k = line_resolve<L_>(L, key);
+        mine[j] = line == AIX_BK_NONE ? S23_NONE : (k.found ? k.slot : (k.overflow ? S23_UND : S23_NONE));
+    };
+    LineRegs<L_> LA, LB;
+    la = key_of(0, ka);
+    line_issue<L_>(ix.bk, la, LA);
+#pragma unroll 1
+    for (int j = 0; j < W; j += 2) {
+        lb = key_of(j + 1, kb);
+        line_issue<L_>(ix.bk, lb, LB);
+        settle(j, LA, ka, la);
+        if (j + 2 < W) { la = key_of(j + 2, ka); line_issue<L_>(ix.bk, la, LA); }
+        settle(j + 1, LB, kb, lb);
+    }
+
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 2
+    for (int i = 0; i < W; ++i) {
+        const uint32_t idx = (uint32_t)i * 64u + lane;
+        uint32_t v = tr[wave][(idx / W) * (W + 1) + (idx % W)];
+        const uint64_t p = wave_first + idx;
+        const bool need = p < nwin && v == S23_UND;                                  // an unmatched window of an overflowed bucket: the MPHF decides
+        if (__ballot(need) != 0ull) {
+            if (need) {
+                uint64_t w0, w1, w2;
+                load23(buf + p, w0, w1, w2);
+                w0 = s23_u_to_t(w0 & 0xDFDFDFDFDFDFDFDFULL);
+                w1 = s23_u_to_t(w1 & 0xDFDFDFDFDFDFDFDFULL);
+                w2 = s23_u_to_t(w2 & 0x00DFDFDFDFDFDFDFULL);
+                const Enc23 e = encode23_words(w0, w1, w2);
+                uint64_t key = e.code;
+                if (canon_mode == 1) { const uint64_t x = revcomp_refx86(e.code, 23); key = e.code < x ? e.code : x; }
+                else if (canon_mode == 2) { const uint64_t x = revcomp(e.code, 23); key = e.code < x ? e.code : x; }
+                uint64_t s0, s1, s2, a, b, c;
+                ascii23_of_rc(revcomp(key, 23), s0, s1, s2);
+                jenkins23(s0, s1, s2, seed, a, b, c);
+                const uint64_t h = mphf_from_hash(ix.m, a, b, c);
+                v = (h < ix.n && ix.keys[h].code == key) ? (uint32_t)h : S23_NONE;
+            }
+        }
+        if (p < nwin) slots[p] = v;
+    }
+}
+
+template <int W, int LPP>
+static hipError_t run23_launch(const IndexDev& ix, const uint8_t* buf, uint64_t len, int canon_mode, uint32_t* slots, hipStream_t s) {
+    const uint64_t nwin = len - 22;
+    const uint64_t per_block = (uint64_t)S23_TB * W;
+    const uint64_t blocks = (nwin + per_block - 1) / per_block;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_run23_slots<W, LPP>), dim3((unsigned)blocks), dim3(S23_TB), 0, s, ix, buf, len, nwin, canon_mode, slots);
+    return hipGetLastError();
+}
+// slots[0, len - 22) through the hash-keyed table with one run of `w` (16 / 32) windows per lane; needs ix.bk
+hipError_t launch_run23_slots(const IndexDev& ix, const uint8_t* buf, uint64_t len, int canon_mode, uint32_t* slots, int w, hipStream_t s) {
+    if (len < 23 || ix.n == 0 || !ix.bk) return hipSuccess;
+    const uint32_t lpp = ix.bk_lpp;
+    if (w == 32) {
+        if (lpp == 8) return run23_launch<32, 8>(ix, buf, len, canon_mode, slots, s);
+        if (lpp == 4) return run23_launch<32, 4>(ix, buf, len, canon_mode, slots, s);
+        if (lpp == 1) return run23_launch<32, 1>(ix, buf, len, canon_mode, slots, s);
+        return run23_launch<32, 2>(ix, buf, len, canon_mode, slots, s);
+    }
+    if (lpp == 8) return run23_launch<16, 8>(ix, buf, len, canon_mode, slots, s);
+    if (lpp == 4) return run23_launch<16, 4>(ix, buf, len, canon_mode, slots, s);
+    if (lpp == 1) return run23_launch<16, 1>(ix, buf, len, canon_mode, slots, s);
+    return run23_launch<16, 2>(ix, buf, len, canon_mode, slots, s);
+}
+
 // windows the table left UNDECIDED: the MPHF path, lane by lane (rare)
 __global__ void __launch_bounds__(256) k_fix23(const IndexDev ix_, const uint8_t* __restrict__ buf, uint64_t nwin, int canon_mode, uint32_t* __restrict__ slots,
                                               const uint32_t* __restrict__ any_undecided) {

@@ -760,7 +760,7 @@ def main():
     ap.add_argument("--seqs", type=int, default=1_000_000, help="sequences of the coverage workloads (config 5: 1 M x 10 kbp)")
     ap.add_argument("--seq-len", type=int, default=10_000)
     ap.add_argument("--table-mib", type=int, default=4096)
-    ap.add_argument("--elem", type=int, default=16)
+    ap.add_argument("--elem", type=int, default=16, help="gather: bytes a lane reads per access (4, 8, 16, 32, 64, 128)")
     ap.add_argument("--unroll", type=int, default=1)
     ap.add_argument("--queries", type=int, default=100_000_000)
     ap.add_argument("--genome", type=int, default=50_000_000)

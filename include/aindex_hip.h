@@ -395,7 +395,7 @@ int aix_pf_build_all_13mers(void** pf_out, uint64_t* pf_len);   /* generate_all_
 int aix_pf_build_codes_dev(const uint64_t* d_codes, uint64_t n, int k, int device, void* stream, void** pf_out, uint64_t* pf_len);
 void aix_free(void* p);
 
-/* Roofline probe: n_access uniform-random reads of elem_bytes (4, 8 or 16) over a table
+/* Roofline probe: n_access uniform-random reads of elem_bytes (4, 8, 16; 32, 64, 128 with unroll 1: the whole element) over a table
  * of n_elems elements in HBM, `unroll` (1 or 4) independent reads in flight per lane. Measurement aid only. */
 int aix_bench_gather_dev(const void* d_table, uint64_t n_elems, int elem_bytes, int unroll, uint64_t n_access,
                          uint64_t seed, uint64_t* d_sink, void* stream);

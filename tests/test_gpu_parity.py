@@ -1597,6 +1597,14 @@ def test_count23_histogram_backend_equals_atomics_and_oracle(canon_case, small23
                         assert np.array_equal(ix.count23_fixed(buf, _lib.FMT_PLAIN, mode), want), (mode, piece, "ranges", bits)
                         assert ix.info["count23_backend"] == 2 and ix.info["count23_passes"] == -(-ix.n // (1 << int(bits)))
                     monkeypatch.delenv("AIX_COUNT23_TEST_RANGE_BITS")
+                    # the run-per-lane probe kernel (k_run23_slots: 16 / 32 consecutive windows per lane, bytes encoded once per run), every lane width
+                    for run in ("16", "32"):
+                        monkeypatch.setenv("AIX_COUNT23_RUN", run)
+                        for lanes in (2, 8, 1, 4):
+                            ix.set_bucket_table(True, lanes)
+                            assert np.array_equal(ix.count23_fixed(buf, _lib.FMT_PLAIN, mode), want), (mode, piece, "run", run, lanes)
+                    monkeypatch.delenv("AIX_COUNT23_RUN")
+                    ix.set_bucket_table(True, 2)
                 ix.set_bucket_table(True)
                 ix.set_minimizer_table(True)
                 monkeypatch.delenv("AIX_COUNT23_PIECE", raising=False)
