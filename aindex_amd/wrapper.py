@@ -30,6 +30,9 @@ def _enc(s) -> bytes:
 _PYFAST = False
 
 
+_PACK_THREADS = max(1, min(16, (os.cpu_count() or 2) // 2))      # worker threads of the list[str] / list[int] conversions
+
+
 def _pyfast():
     """The optional CPython helper built next to the library (csrc/aix_pyfast.c); None when it is not there."""
     global _PYFAST
@@ -239,11 +242,38 @@ class AindexWrapper:
         return self.get_tf_values([kmer])[0]                                            # :644-651
 
     @staticmethod
+    def _packed(kmers, k: int):
+        """A batch that is ALREADY one buffer of N*k ASCII bytes — bytes / bytearray / memoryview, a numpy 'S<k>' or (N, k) uint8 array,
+        or ONE str of N*k characters — as that buffer (no per-item Python work), else None. (A str of exactly k characters is one query,
+        a longer one whose length is a multiple of k is the joined batch.)"""
+        if isinstance(kmers, (bytes, bytearray, memoryview)):
+            return kmers if len(kmers) % k == 0 else None
+        if isinstance(kmers, str):
+            if len(kmers) % k or not kmers.isascii():
+                return None
+            return kmers.encode("ascii")
+        if isinstance(kmers, np.ndarray):
+            if kmers.dtype.kind == "S" and kmers.dtype.itemsize == k:
+                return np.ascontiguousarray(kmers).view(np.uint8).reshape(-1)
+            if kmers.dtype == np.uint8 and (kmers.ndim == 1 or (kmers.ndim == 2 and kmers.shape[1] == k)) and kmers.size % k == 0:
+                return np.ascontiguousarray(kmers).reshape(-1)
+        return None
+
+    @staticmethod
+    def _to_list(a: np.ndarray) -> List[int]:
+        """uint32 answers as the list[int] the reference returns; values up to 256 (nearly every term frequency) are filled in by worker
+        threads from CPython's cached small ints (csrc/aix_pyfast.c: u32_list), ndarray.tolist() otherwise."""
+        fast = _pyfast()
+        if fast is not None and hasattr(fast, "u32_list") and a.dtype == np.uint32 and a.flags.c_contiguous:
+            return fast.u32_list(a, a.shape[0], _PACK_THREADS)
+        return a.tolist()
+
+    @staticmethod
     def _join_fixed(kmers, k: int):
         """One bytes object of len(kmers)*k bytes when every item is a k-character str/bytes, else None."""
         fast = _pyfast()
         if fast is not None:
-            flat = fast.join_fixed(kmers, k)                     # C loop over the list: no intermediate str / bytes objects
+            flat = fast.join_fixed(kmers, k, _PACK_THREADS)      # C loop over the list (worker threads read the items' buffers): no intermediate str / bytes objects
             if flat is not None or not kmers:
                 return flat
             # not all-ASCII k-character items: let the exact Python rules below decide (latin-1 characters are still one byte)
@@ -259,12 +289,16 @@ class AindexWrapper:
         return flat
 
     def get_tf_values_23mer(self, kmers: List[str]) -> List[int]:
-        if not kmers:
+        if len(kmers) == 0:
             return []
-        flat = self._join_fixed(kmers, 23)                                              # common case: all 23-mers
+        flat = self._packed(kmers, 23)                                                  # one buffer of N*23 bytes: nothing to do per item
+        if flat is None and not isinstance(kmers, (str, bytes, bytearray, memoryview, np.ndarray)):
+            flat = self._join_fixed(kmers, 23)                                          # common case: a list of 23-mers
         if flat is not None:
-            return self._need23().tf_ascii(flat).tolist()
-        return self._need23().tf_ragged(kmers).tolist()                                 # :1219-1228, any lengths
+            return self._to_list(self._need23().tf_ascii(flat))
+        if isinstance(kmers, (str, bytes, bytearray, memoryview)):
+            kmers = [kmers]                                                             # one query of another length
+        return self._to_list(self._need23().tf_ragged(kmers))                           # :1219-1228, any lengths
 
     def get_tf_value_23mer(self, kmer: str) -> int:
         return self.get_tf_values_23mer([kmer])[0]
@@ -273,12 +307,16 @@ class AindexWrapper:
         """:938-980 (defined but not bound in the reference, although aindex.py:148 calls it)."""
         if not self._is_13mer_mode:
             return [0] * len(kmers)
-        if not kmers:
+        if len(kmers) == 0:
             return []
-        flat = self._join_fixed(kmers, 13)
+        flat = self._packed(kmers, 13)
+        if flat is None and not isinstance(kmers, (str, bytes, bytearray, memoryview, np.ndarray)):
+            flat = self._join_fixed(kmers, 13)
         if flat is not None:
-            return self._ix13.tf_ascii(flat).tolist()
-        return self._ix13.tf_ragged(kmers).tolist()
+            return self._to_list(self._ix13.tf_ascii(flat))
+        if isinstance(kmers, (str, bytes, bytearray, memoryview)):
+            kmers = [kmers]
+        return self._to_list(self._ix13.tf_ragged(kmers))
 
     def get_tf_value_13mer(self, kmer: str) -> int:
         return self.get_tf_values_13mer([kmer])[0] if self._is_13mer_mode and self._ix13 else 0

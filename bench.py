@@ -725,6 +725,8 @@ def measure_count23_strong(ix, g, rank, world, dev, total_reads, steps, warmup):
             "allreduce_ms": ar_ms, "allreduce_bytes": 4 * ix.n, "collective": f"all_reduce(sum) of int32 tf[{ix.n}]" if backend != "none" else "none (1 rank)",
             "backend": backend, "collective_ranks": world if backend != "none" else 1,
             "kernel": "k_count23_fixed", "kernel_ms_this_rank": k_ms, "windows_this_rank": windows_rank,
+            "counting_backend": {1: "memory-side atomics", 2: "slot stream + LDS histogram"}.get(ix.info["count23_backend"], "none"),
+            "histogram_passes": ix.info["count23_passes"],
             "windows_counted_all_ranks": digest["sum"], "tf_digest": digest,
             "one_device_rehearsal": bool(os.environ.get("AIX_BENCH_ONE_DEVICE"))}
 
@@ -874,11 +876,19 @@ def main():
                 tf13 = torch.empty(4 ** 13, dtype=torch.int64, device=f"cuda:{dev}")
                 w13, k13, _ = timed_steps(lambda: adist.count13_sharded_t(ix13, reads13, tf13), 3, 1, dev)
                 total13 = int(tf13.sum().item())
-                ar13, _, _ = timed_steps(lambda: adist.all_reduce_sum_(tf13), 3, 1, dev) if world > 1 else (0.0, 0.0, [])
+                bits13 = 0
+                if world > 1:                                  # the table crosses the links as u32 (256 MiB) when no counter can reach 2^32
+                    probe13 = tf13 // world                    # same magnitude as one rank's table
+                    bits13 = adist.all_reduce_sum_u64_narrow_(probe13)[1]
+                    ar13, _, _ = timed_steps(lambda: adist.all_reduce_sum_u64_narrow_(probe13.clone()), 3, 1, dev)
+                    del probe13
+                else:
+                    ar13 = 0.0
                 sec["count13_dense"] = {"metric": "reads_per_sec_13mer_count", "value": world * a.reads13 * 3 / w13, "unit": "reads/s", "scaling": "weak",
                                         "reads_per_step_per_gpu": a.reads13, "ms_per_step": w13 / 3 * 1e3, "allreduce_ms_of_it": ar13 / 3 * 1e3,
                                         "windows_counted_all_ranks": total13,
-                                        "collective": "all_reduce(sum) of int64 tf[4^13]" if world > 1 else "none (1 rank)"}
+                                        "collective": (f"all_reduce(sum) of tf[4^13] as u{bits13} ({(4 ** 13) * bits13 // 8 >> 20} MiB per rank)" if world > 1 else "none (1 rank)"),
+                                        "collective_ranks": world, "backend": (torch.distributed.get_backend() if world > 1 else "none")}
                 ix13.close()
                 del reads13, tf13, g13
             except Exception as e:  # pragma: no cover
@@ -987,6 +997,7 @@ def main():
                                            "histogram against the fixed MPHF index + all-reduce(sum) of tf[]",
                                "total_reads": a.total_reads, "reads_this_rank": r["reads_this_rank"], "index_keys": ix.n, "genome_bp": a.genome,
                                "parallelism": f"reads sharded x{world}, index replicated", "backend": r["backend"], "collective": r["collective"],
+                               "counting_backend": r["counting_backend"], "histogram_passes": r["histogram_passes"],
                                "collective_ranks": r["collective_ranks"], "one_device_rehearsal": r["one_device_rehearsal"]},
                     **({"same_workload_on_one_gpu": r["same_workload_on_one_gpu"]} if "same_workload_on_one_gpu" in r else {}),
                     "allreduce_ms": r["allreduce_ms"], "allreduce_bytes": r["allreduce_bytes"], "tf_digest": r["tf_digest"],

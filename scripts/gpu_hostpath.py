@@ -22,11 +22,31 @@ assert np.array_equal(r, r2)
 # python list[str] surface on the same handle
 w = AindexWrapper()
 w._ix23 = ix
-M = 5_000_000
-strs = [bytes(x).decode() for x in q[: 23 * M].reshape(-1, 23)]
-t = time.perf_counter(); res = w.get_tf_values(strs); dt = time.perf_counter() - t
-out["AindexWrapper.get_tf_values(list[str])"] = {"queries": M, "seconds": dt, "lookups_per_s": M / dt}
+M = 20_000_000
+joined = q[: 23 * M].tobytes().decode()
+strs = [joined[i * 23:(i + 1) * 23] for i in range(M)]                      # 20 M str objects (the call the reference's metric is quoted on takes these)
+best = None
+for _ in range(3):
+    t = time.perf_counter(); res = w.get_tf_values(strs); dt = time.perf_counter() - t
+    best = dt if best is None or dt < best else best
+out["AindexWrapper.get_tf_values(list[str])"] = {"queries": M, "seconds": best, "lookups_per_s": M / best, "answers": "all 0 (Q_rand): cached small ints"}
 assert res == r[:M].tolist()
+# the same call on a query set with hits (term frequencies 1 .. 255 are cached small ints too, larger ones are boxed one by one)
+gw = engine.synth_mix23_t(8, g, M).cpu().numpy()
+joined2 = gw.tobytes().decode()
+strs2 = [joined2[i * 23:(i + 1) * 23] for i in range(M)]
+best2 = None
+for _ in range(3):
+    t = time.perf_counter(); res_mix = w.get_tf_values(strs2); dt = time.perf_counter() - t
+    best2 = dt if best2 is None or dt < best2 else best2
+out["AindexWrapper.get_tf_values(list[str]) Q_mix"] = {"queries": M, "seconds": best2, "lookups_per_s": M / best2, "nonzero_fraction": sum(1 for v in res_mix[:100000] if v) / 100000}
+assert res_mix == ix.tf_ascii(gw).tolist()
+del strs2, joined2
+# packed inputs through the same method: one bytes object / one joined str / a numpy 'S23' array — no per-item work on the way in
+for name, arg in (("bytes", q[: 23 * M].tobytes()), ("joined str", joined), ("numpy S23", q[: 23 * M].view("S23"))):
+    t = time.perf_counter(); res3 = w.get_tf_values(arg); dt = time.perf_counter() - t
+    out[f"AindexWrapper.get_tf_values({name})"] = {"queries": M, "seconds": dt, "lookups_per_s": M / dt}
+    assert res3 == res
 t = time.perf_counter(); res2 = w.get_tf_values_array(q[: 23 * M]); dt = time.perf_counter() - t
 out["AindexWrapper.get_tf_values_array(uint8[N,23])"] = {"queries": M, "seconds": dt, "lookups_per_s": M / dt}
 print(json.dumps(out, indent=1))

@@ -618,6 +618,24 @@ def test_python_mirrors(gold, small23_prefix, tmp_path):
     assert [ai.get_kid_by_kmer(s) for s in qs[:30]] == q["kid"][:30]
     assert len(ai) == q["hash_size"] and ai.n_kmers == q["n_kmers"]
     w = ai._wrapper
+    # the batch surface on every shape a batch can arrive in: list[str], list[bytes], a tuple, ONE buffer of N * 23 bytes
+    # (bytes / bytearray / memoryview / numpy 'S23' / numpy uint8), ONE joined str; a batch above the thread threshold of the C helper; and
+    # values above CPython's small-int cache (256) in the list the call returns
+    fixed = [s for s in qs if len(s) == 23 and s.isascii()]
+    want = [t for s, t in zip(qs, q["tf"]) if len(s) == 23 and s.isascii()]
+    assert len(fixed) > 1000 and any(want)
+    joined = "".join(fixed)
+    for arg in (fixed, [s.encode() for s in fixed], tuple(fixed), joined.encode(), bytearray(joined.encode()), memoryview(joined.encode()),
+                np.array([s.encode() for s in fixed], dtype="S23"), np.frombuffer(joined.encode(), dtype=np.uint8), joined):
+        got = w.get_tf_values(arg)
+        assert isinstance(got, list) and got == want, type(arg)
+    assert w.get_tf_values(fixed[0]) == [want[0]] and w.get_tf_values(fixed[0][:20]) == [0] and w.get_tf_values([]) == [] and w.get_tf_values("") == []
+    big = fixed * (250_000 // len(fixed) + 1)
+    assert w.get_tf_values(big) == want * (250_000 // len(fixed) + 1)
+    from aindex_amd.wrapper import AindexWrapper as _W
+    vals = np.array([0, 1, 255, 256, 257, 65536, 2 ** 32 - 1] * 40_000, dtype=np.uint32)
+    lst = _W._to_list(vals)
+    assert lst == vals.tolist() and all(type(v) is int for v in lst[:14])
     assert w.get_total_tf_values_23mer(qs) == q["total"]
     assert [list(p) for p in w.get_tf_both_directions_23mer_batch(qs)] == q["both"]
     for c in q["coverage"]:
