@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(A2_FB, 6) k_a2_final(const IndexDev ix, const 
                 if (s < R && h < n && n_n) {
                     n_ind[j] = indices[h];
                     n_fl[j] = filled[h];
-                    n_tf[j] = k13 ? ix.tf13_mphf[h] : (uint64_t)ix.keys[h].tf;
+                    n_tf[j] = k13 ? ix.tf13_mphf[h] : (uint64_t)key_at(ix, h).tf;
                 }
             }
         }
@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(256) k_a2_place64(const IndexDev ix, const uin
         const uint64_t e = sorted[j];
         const uint32_t h = (uint32_t)(e >> 32);
         const uint64_t rank = (uint64_t)filled[h] + (j - first[h]);
-        const uint64_t tf = k13 ? ix.tf13_mphf[h] : (uint64_t)ix.keys[h].tf;
+        const uint64_t tf = k13 ? ix.tf13_mphf[h] : (uint64_t)key_at(ix, h).tf;
         if (rank < tf) positions[indices[h] + rank] = piece_first + (uint32_t)e + 1;
     }
 }

@@ -152,6 +152,8 @@ static void destroy(aix_index* h) {
     if (h->recs) (void)hipFree(h->recs);
     if (h->ee) (void)hipFree(h->ee);
     if (h->keys) (void)hipFree(h->keys);
+    if (h->side) (void)hipFree(h->side);
+    if (h->unfiled) (void)hipFree(h->unfiled);
     if (h->bk) (void)hipFree(h->bk);
     if (h->bloom) (void)hipFree(h->bloom);
     if (h->mk) (void)hipFree(h->mk);
@@ -183,7 +185,7 @@ static int build_bucket_table(aix_index* h, hipStream_t s) {
     if (const char* e = getenv("AIX_BUCKET_LOAD")) { const double v = atof(e); if (v >= 0.25 && v <= 8.0) load = v; }
     if (const char* e = getenv("AIX_BUCKET_LANES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) { h->bk_lpp = (uint32_t)v; h->bk_lpp_set = true; } }
     uint64_t nb = (uint64_t)((double)h->n / load) + 1;
-    if (nb > 0xFFFFFFF0ull) nb = 0xFFFFFFF0ull;
+    if (nb > 0x0FFFFFF0ull) nb = 0x0FFFFFF0ull;                                // entry indices (8 per bucket) share a word with the "unfiled" flag of the side index
     const uint64_t bytes = nb * 8 * sizeof(BkEntry);
     DevBuf fill(s);
     HIPCHK(fill.alloc_once(4 * nb));
@@ -218,7 +220,9 @@ static int build_bucket_table(aix_index* h, hipStream_t s) {
     DevBuf mfill(s);
     HIPCHK(mfill.alloc_once(4 * (nbm + 1)));
     HIPCHK(hipMemsetAsync(mfill.p, 0, 4 * (nbm + 1), s));
-    HIPCHK(launch_build_buckets(h->dev().m, h->keys, h->n, h->bk, h->nb, (uint32_t*)fill.p, h->bloom, h->nbloom, (uint32_t)nbm, (uint32_t*)mfill.p, s));
+    HIPCHK(hipMalloc((void**)&h->side, 4 * h->n));
+    h->device_bytes += 4 * h->n;
+    HIPCHK(launch_build_buckets(h->dev().m, h->keys, h->n, h->bk, h->nb, (uint32_t*)fill.p, h->bloom, h->nbloom, (uint32_t)nbm, (uint32_t*)mfill.p, h->side, s));
     h->mk_cap = AIX_MK_ENTRIES;
     if (const char* e = getenv("AIX_MINIMIZER_CAP")) { const int v = atoi(e); if (v >= 1 && v <= AIX_MK_ENTRIES) h->mk_cap = (uint32_t)v; }   // test hook: short buckets -> many undecided windows
     if (want_mk) {
@@ -251,6 +255,38 @@ static int build_bucket_table(aix_index* h, hipStream_t s) {
     uint64_t unfiled = 0;
     for (uint64_t i = 0; i < nb; ++i) if (f[i] > 8) unfiled += f[i] - 8;
     h->bk_unfiled = unfiled;
+    // The keys the table does not hold (beyond the eighth of their bucket, or not in their own MPHF slot) are closed up into `unfiled`; with
+    // the side index every slot's {code, tf} is then reachable without the 16 B-per-key record array, which goes back to the driver.
+    {
+        DevBuf cnt(s);
+        HIPCHK(cnt.alloc_once(8));
+        HIPCHK(hipMemsetAsync(cnt.p, 0, 8, s));
+        HIPCHK(launch_count_unfiled(h->side, h->n, (uint32_t*)cnt.p, s));
+        uint32_t nu = 0;
+        HIPCHK(hipMemcpyAsync(&nu, cnt.p, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipMalloc((void**)&h->unfiled, sizeof(KeyRec) * (uint64_t)(nu ? nu : 1)));
+        h->n_unfiled = nu;
+        h->device_bytes += sizeof(KeyRec) * (uint64_t)nu;
+        HIPCHK(launch_side_unfiled(h->keys, h->n, h->side, h->unfiled, (uint32_t*)cnt.p + 1, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    return AIX_OK;
+}
+
+// presence masks of the early-exit MPHF walk (aix_device.hpp: EeRec), from the handle's keys
+static int build_early_exit_table(aix_index* h, hipStream_t s) {
+    if (h->ee || h->n == 0) return AIX_OK;
+    const uint64_t nrec = (h->B + 15) / 16;
+    HIPCHK(hipMalloc((void**)&h->ee, sizeof(EeRec) * (nrec ? nrec : 1)));
+    h->device_bytes += sizeof(EeRec) * nrec;
+    EeRec* ee = h->ee;
+    h->ee = nullptr;                                                            // not visible to dev() until it is complete
+    const hipError_t e = launch_set_fingerprints(h->dev(), h->recs, ee, false, s);
+    const hipError_t e2 = hipStreamSynchronize(s);
+    h->ee = ee;
+    HIPCHK(e);
+    HIPCHK(e2);
     return AIX_OK;
 }
 
@@ -269,13 +305,22 @@ static int adopt_device_arrays(aix_index* h, const uint64_t* d_checker, const ui
     (void)hipFree(d_flag);
     HIPCHK(e);
     h->canonical_only = (flag == 0);
-    const uint64_t nrec = (h->B + 15) / 16;
-    HIPCHK(hipMalloc((void**)&h->ee, sizeof(EeRec) * (nrec ? nrec : 1)));
-    h->device_bytes += sizeof(EeRec) * nrec;
-    HIPCHK(launch_set_fingerprints(h->dev().m, h->recs, h->ee, h->keys, n, s));
+    // The early-exit table (32 B per 16 bit-pairs: 2.5 B per key) serves the MPHF walk; with a verification table in front that walk only runs
+    // behind overflowed buckets, so the table is then built on request (aix_index_set_early_exit) instead of at every open.
+    bool want_table = true;
+    if (const char* e = getenv("AIX_BUCKET_TABLE")) want_table = atoi(e) != 0;
+    if (!want_table) { const int st = build_early_exit_table(h, s); if (st) return st; }
+    HIPCHK(launch_set_fingerprints(h->dev(), h->recs, nullptr, true, s));
     HIPCHK(hipStreamSynchronize(s));
     h->has_fp = true;
-    return build_bucket_table(h, s);
+    const int st = build_bucket_table(h, s);
+    if (st) return st;
+    if (h->bk && h->side) {                                                     // every key is reachable through the table / the unfiled list: drop the duplicate
+        (void)hipFree(h->keys);
+        h->keys = nullptr;
+        h->device_bytes -= sizeof(KeyRec) * n;
+    }
+    return AIX_OK;
 }
 
 extern "C" int aix_index_create_23(const void* pf_bytes, uint64_t pf_len, const uint64_t* checker, const uint32_t* tf, uint64_t n, int device,
@@ -512,6 +557,11 @@ extern "C" int aix_index_set_fingerprint_filter(aix_index_t* h, int enabled) {
 extern "C" int aix_index_set_early_exit(aix_index_t* h, int enabled) {
     if (!h) return AIX_ERR_ARG;
     h->early_exit = enabled != 0;
+    if (enabled && h->k == 23 && h->has_fp && !h->ee) {                         // first request on a handle that was opened with a verification table
+        DevGuard g(h->device);
+        const int st = build_early_exit_table(h, 0);
+        if (st) return st;
+    }
     return AIX_OK;
 }
 
@@ -557,7 +607,7 @@ extern "C" int aix_index_get_tf(const aix_index_t* h, void* out, uint64_t out_by
     if (h->n == 0) return AIX_OK;
     uint32_t* d = nullptr;
     HIPCHK(hipMalloc((void**)&d, 4 * h->n));
-    hipError_t e = launch_extract_tf(h->keys, h->n, d, nullptr, 0);
+    hipError_t e = launch_extract_tf(h->dev(), d, nullptr, 0);
     if (e == hipSuccess) e = hipMemcpy(out, d, 4 * h->n, hipMemcpyDeviceToHost);
     (void)hipFree(d);
     HIPCHK(e);
@@ -572,7 +622,7 @@ extern "C" int aix_index_get_checker(const aix_index_t* h, uint64_t* out, uint64
     DevGuard g(h->device);
     uint64_t* d = nullptr;
     HIPCHK(hipMalloc((void**)&d, 8 * h->n));
-    hipError_t e = launch_extract_tf(h->keys, h->n, nullptr, d, 0);
+    hipError_t e = launch_extract_tf(h->dev(), nullptr, d, 0);
     if (e == hipSuccess) e = hipMemcpy(out, d, 8 * h->n, hipMemcpyDeviceToHost);
     (void)hipFree(d);
     HIPCHK(e);

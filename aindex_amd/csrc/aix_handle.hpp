@@ -58,7 +58,10 @@ struct aix_index {
     // HBM
     BvRec* recs = nullptr;
     EeRec* ee = nullptr;                       // early-exit table (23-mer handles with keys)
-    KeyRec* keys = nullptr;
+    KeyRec* keys = nullptr;                    // checker[] / tf[] interleaved: while the handle is built, and afterwards only when no verification table was built
+    uint32_t* side = nullptr;                  // with a table: slot -> table entry | AIX_SIDE_UNFILED + index into `unfiled` (4 B per key instead of 16)
+    KeyRec* unfiled = nullptr;                 // the keys the table does not hold (~1 %)
+    uint64_t n_unfiled = 0;
     BkEntry* bk = nullptr;                     // verification table: nb buckets of eight {code, tf, slot} entries (one 128-byte line each)
     uint32_t nb = 0;
     uint32_t bk_lpp = 8;                       // lanes that share one bucket read
@@ -98,7 +101,7 @@ struct aix_index {
     bool canonical_fastpath = true;
     bool has_fp = false;
     bool fp_filter = true;
-    bool early_exit = true;
+    bool early_exit = true;                    // (used when the early-exit table exists: built at open only without a verification table, else on request)
     std::mutex count_mutex;
     uint32_t c23_backend = 0, c23_passes = 0;     // the last aix_count23_fixed*: 1 = memory-side atomics, 2 = slot stream + LDS histogram; passes over the slot stream
     bool c13_atomics = false, c13_added = false;   // state of a 13-mer count in progress (between count13_begin_locked and count13_end_locked)
@@ -118,6 +121,9 @@ struct aix_index {
         d.m.nrecs = (B + 15) / 16;
         d.m.fm = make_fastmod(D);
         d.keys = keys;
+        d.side = side;
+        d.bk_store = bk;
+        d.unfiled = unfiled;
         d.n = n;
         d.tf13_code = tf13_code;
         d.tf13_mphf = tf13_mphf;

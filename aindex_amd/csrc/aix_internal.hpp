@@ -10,7 +10,13 @@ namespace aix {
 // what kernels receive by value
 struct IndexDev {
     MphfDev m;
-    const KeyRec* keys;       // 23-mer: n records {code, tf}
+    const KeyRec* keys;       // 23-mer: n records {code, tf} — only while an index is being built, or when no verification table was built
+    // 23-mer with a verification table: checker[h] / tf[h] are NOT stored a second time. side[h] says where slot h's key lives: an entry of
+    // the table (filed keys: 99 %), or — top bit set — a record of `unfiled` (keys beyond the eighth of their bucket, keys that are not in
+    // their own MPHF slot). key_at() below is the one accessor.
+    const uint32_t* side;
+    const BkEntry* bk_store;  // the table's storage (also when the table is switched off for probing)
+    const KeyRec* unfiled;
     uint64_t n;               // 23-mer: number of keys; 13-mer: 4^13
     const uint64_t* tf13_code;  // 13-mer: tf in 2-bit-code order (u64[4^13])
     const uint64_t* tf13_mphf;  // 13-mer: tf in mphf order (the file's order)
@@ -29,6 +35,20 @@ struct IndexDev {
     const uint32_t* mk_off;   // nbm + 1 offsets into mk (a bucket = all filed keys whose minimizer hashes to it: no bucket overflows at build time)
     uint32_t mk_cap;          // entries of a bucket a lane reads (<= AIX_MK_ENTRIES); a longer bucket leaves its windows to the hash-keyed table
 };
+
+#define AIX_SIDE_UNFILED 0x80000000u
+// checker[h] and tf[h] of PHASH_MAP (hash.hpp:82-121) for slot h < n
+__device__ __forceinline__ KeyRec key_at(const IndexDev& ix, uint64_t h) {
+    if (ix.keys) return ix.keys[h];
+    const uint32_t s = ix.side[h];
+    if (s & AIX_SIDE_UNFILED) return ix.unfiled[s & ~AIX_SIDE_UNFILED];
+    const BkEntry e = ix.bk_store[s];
+    KeyRec r;
+    r.code = (uint64_t)e.code_lo | ((uint64_t)(e.code_hi & 0x3FFFu) << 32);
+    r.tf = e.tf;
+    r.pad = 0;
+    return r;
+}
 
 enum LookupMode { MODE_TF = 0, MODE_HASH = 1, MODE_KIDSTRAND = 2, MODE_BOTH = 3, MODE_TOTAL = 4, MODE_LINES = 5 };
 
@@ -55,18 +75,23 @@ hipError_t launch_coverage(const IndexDev& ix, const uint8_t* seqs, const uint64
 
 // index construction helpers
 hipError_t launch_build_keyrecs(const uint64_t* checker, const uint32_t* tf, uint64_t n, KeyRec* recs, uint32_t* noncanon_count, hipStream_t s);
-hipError_t launch_set_fingerprints(const MphfDev& m, BvRec* recs_rw, EeRec* ee_rw, const KeyRec* keys, uint64_t n, hipStream_t s);
+// fp nibbles of the MPHF records (do_fp) and / or the presence masks of the early-exit table (ee_rw non-null, initialised here); keys through key_at(ix, .)
+hipError_t launch_set_fingerprints(const IndexDev& ix, BvRec* recs_rw, EeRec* ee_rw, bool do_fp, hipStream_t s);
 // verification table: bk (nb * 8 entries) is initialised and filled from the keys that sit in their own MPHF slot;
 // fill = nb zeroed u32 counters (scratch)
 hipError_t launch_build_buckets(const MphfDev& m, const KeyRec* keys, uint64_t n, BkEntry* bk, uint32_t nb, uint32_t* fill, uint64_t* bloom /* zeroed, nullable */,
-                                uint32_t nbloom, uint32_t nbm /* 0: no minimizer-keyed copy */, uint32_t* mfill /* nbm zeroed words: keys per minimizer bucket */, hipStream_t s);
+                                uint32_t nbloom, uint32_t nbm /* 0: no minimizer-keyed copy */, uint32_t* mfill /* nbm zeroed words: keys per minimizer bucket */,
+                                uint32_t* side /* n words: entry index of every filed key, 0xFFFFFFFF for the others */, hipStream_t s);
+// the keys the table does not hold, closed up: unfiled[idx] = keys[i], side[i] = AIX_SIDE_UNFILED | idx for every side[i] == 0xFFFFFFFF; *counter = zeroed word
+hipError_t launch_side_unfiled(const KeyRec* keys, uint64_t n, uint32_t* side, KeyRec* unfiled, uint32_t* counter, hipStream_t s);
+hipError_t launch_count_unfiled(const uint32_t* side, uint64_t n, uint32_t* counter, hipStream_t s);
 // second pass of the minimizer-keyed copy: entries written at mk[off[bucket] + arrival]; mcur = nbm zeroed words
 hipError_t launch_fill_minimizer_table(const MphfDev& m, const KeyRec* keys, uint64_t n, BkEntry* mk, const uint32_t* off, uint32_t nbm, uint32_t* mcur, hipStream_t s);
 hipError_t launch_scatter23(const MphfDev& m, uint64_t n, uint64_t nslots, const uint8_t* keys_ascii /* or */, const uint64_t* codes, const uint32_t* counts,
                             uint64_t* checker, uint32_t* tf, uint32_t* occupied_bits, uint32_t* conflict, hipStream_t s);
 hipError_t launch_perm13(const MphfDev& m, uint32_t* perm /* [4^13]: code -> mphf index */, hipStream_t s);
 hipError_t launch_tf13_to_code_order(const uint32_t* perm, const uint64_t* tf_mphf, uint64_t* tf_code, hipStream_t s);
-hipError_t launch_extract_tf(const KeyRec* recs, uint64_t n, uint32_t* tf, uint64_t* checker, hipStream_t s);
+hipError_t launch_extract_tf(const IndexDev& ix, uint32_t* tf, uint64_t* checker, hipStream_t s);
 
 // counting
 hipError_t launch_count13_plain(const uint8_t* buf, uint64_t len, unsigned long long* table_code /* [4^13] */, hipStream_t s);

@@ -58,7 +58,7 @@ __device__ __forceinline__ Probe probe23_mphf(const IndexDev& ix, uint64_t a, ui
         r.slot = mphf_from_hash(ix.m, a, b, c);
     }
     if (r.slot < ix.n) {                           // python_wrapper.cpp:613 `h1 >= n ||`
-        const KeyRec k = ix.keys[r.slot];
+        const KeyRec k = key_at(ix, r.slot);
         r.lines += 16;
         if (k.code == code) { r.found = true; r.tf = k.tf; }
     }
@@ -470,10 +470,10 @@ __global__ void __launch_bounds__(kBlock) k_build_keyrecs(const uint64_t* __rest
     }
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicAdd(noncanon, 1u);
 }
-__global__ void __launch_bounds__(kBlock) k_extract(const KeyRec* __restrict__ recs, uint64_t n, uint32_t* __restrict__ tf, uint64_t* __restrict__ checker) {
+__global__ void __launch_bounds__(kBlock) k_extract(const IndexDev ix, uint32_t* __restrict__ tf, uint64_t* __restrict__ checker) {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        const KeyRec r = recs[i];
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < ix.n; i += stride) {
+        const KeyRec r = key_at(ix, i);
         if (tf) tf[i] = r.tf;
         if (checker) checker[i] = r.code;
     }
@@ -492,17 +492,19 @@ __global__ void __launch_bounds__(kBlock) k_init_ee(const BvRec* __restrict__ re
         ee[i] = e;
     }
 }
-__global__ void __launch_bounds__(kBlock) k_set_fp(const MphfDev m, BvRec* __restrict__ recs, EeRec* __restrict__ ee, const KeyRec* __restrict__ keys, uint64_t n) {
+__global__ void __launch_bounds__(kBlock) k_set_fp(const IndexDev ix, BvRec* __restrict__ recs, EeRec* __restrict__ ee, int do_fp) {
+    const MphfDev& m = ix.m;
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        const uint64_t code = keys[i].code;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < ix.n; i += stride) {
+        const uint64_t code = key_at(ix, i).code;
         if (code >> 46) continue;
         uint64_t w0, w1, w2, a, b, c, node;
         uint32_t fps;
         ascii23_of_rc(revcomp(code, 23), w0, w1, w2);
         jenkins23(w0, w1, w2, m.seed, a, b, c);
         if (mphf_from_hash_fp(m, a, b, c, fps, node) != i) continue;
-        atomicOr((unsigned long long*)&recs[node >> 4].fp, (unsigned long long)fp_of_hash(a, b, c) << (4 * (uint32_t)(node & 15)));
+        if (do_fp) atomicOr((unsigned long long*)&recs[node >> 4].fp, (unsigned long long)fp_of_hash(a, b, c) << (4 * (uint32_t)(node & 15)));
+        if (!ee) continue;
         const uint64_t nd[3] = {fastmod(a, m.fm), m.D + fastmod(b, m.fm), 2 * m.D + fastmod(c, m.fm)};
 #pragma unroll
         for (int t = 0; t < 3; ++t) {                     // the key's two presence bits at each of its three nodes
@@ -527,10 +529,12 @@ __global__ void __launch_bounds__(kBlock) k_bk_init(BkEntry* __restrict__ bk, ui
     }
 }
 __global__ void __launch_bounds__(kBlock) k_bk_fill(const MphfDev m, const KeyRec* __restrict__ keys, uint64_t n, BkEntry* __restrict__ bk, uint32_t nb,
-                                                   uint32_t* __restrict__ fill, uint64_t* __restrict__ bloom, uint32_t nbloom, uint32_t nbm, uint32_t* __restrict__ mfill) {
+                                                   uint32_t* __restrict__ fill, uint64_t* __restrict__ bloom, uint32_t nbloom, uint32_t nbm, uint32_t* __restrict__ mfill,
+                                                   uint32_t* __restrict__ side) {
     const uint64_t stride = (uint64_t)gridDim.x * kBlock;
     for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         const KeyRec kr = keys[i];
+        side[i] = 0xFFFFFFFFu;                                   // not filed until the entry has been written below
         if (kr.code >> 46) continue;
         uint64_t w0, w1, w2, a, b, c;
         ascii23_of_rc(revcomp(kr.code, 23), w0, w1, w2);
@@ -541,7 +545,7 @@ __global__ void __launch_bounds__(kBlock) k_bk_fill(const MphfDev m, const KeyRe
         const uint32_t pos = atomicAdd(&fill[bi], 1u);
         BkEntry e;
         e.code_lo = (uint32_t)kr.code; e.code_hi = (uint32_t)(kr.code >> 32); e.tf = kr.tf; e.slot = (uint32_t)i;
-        if (pos < 8u) bk[(uint64_t)bi * 8 + pos] = e;
+        if (pos < 8u) { bk[(uint64_t)bi * 8 + pos] = e; side[i] = bi * 8u + pos; }      // (nb * 8 < 2^31: nb = n / load + 1 with n < 2^32 ... checked by the caller)
         if (nbm) atomicAdd(&mfill[mk_home(minimizer23(kr.code, revcomp(kr.code, 23)), nbm)], 1u);    // the minimizer-keyed copy: sized here, written by k_mk_fill
     }
 }
@@ -562,6 +566,22 @@ __global__ void __launch_bounds__(kBlock) k_mk_fill(const MphfDev m, const KeyRe
         BkEntry e;
         e.code_lo = (uint32_t)kr.code; e.code_hi = (uint32_t)(kr.code >> 32); e.tf = kr.tf; e.slot = (uint32_t)i;
         mk[(uint64_t)off[home] + atomicAdd(&mcur[home], 1u)] = e;
+    }
+}
+__global__ void __launch_bounds__(kBlock) k_side_count(const uint32_t* __restrict__ side, uint64_t n, uint32_t* __restrict__ counter) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    uint32_t c = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) c += side[i] == 0xFFFFFFFFu ? 1u : 0u;
+    if (c) atomicAdd(counter, c);
+}
+__global__ void __launch_bounds__(kBlock) k_side_unfiled(const KeyRec* __restrict__ keys, uint64_t n, uint32_t* __restrict__ side, KeyRec* __restrict__ unfiled,
+                                                        uint32_t* __restrict__ counter) {
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        if (side[i] != 0xFFFFFFFFu) continue;
+        const uint32_t idx = atomicAdd(counter, 1u);
+        unfiled[idx] = keys[i];
+        side[i] = AIX_SIDE_UNFILED | idx;
     }
 }
 __global__ void __launch_bounds__(kBlock) k_bk_flag(BkEntry* __restrict__ bk, uint32_t nb, const uint32_t* __restrict__ fill) {
@@ -950,21 +970,29 @@ hipError_t launch_build_keyrecs(const uint64_t* checker, const uint32_t* tf, uin
     if (n == 0) return hipSuccess;
     AIX_LAUNCH(k_build_keyrecs, n, s, checker, tf, n, recs, noncanon);
 }
-hipError_t launch_extract_tf(const KeyRec* recs, uint64_t n, uint32_t* tf, uint64_t* checker, hipStream_t s) {
-    if (n == 0) return hipSuccess;
-    AIX_LAUNCH(k_extract, n, s, recs, n, tf, checker);
+hipError_t launch_extract_tf(const IndexDev& ix, uint32_t* tf, uint64_t* checker, hipStream_t s) {
+    if (ix.n == 0) return hipSuccess;
+    AIX_LAUNCH(k_extract, ix.n, s, ix, tf, checker);
 }
-hipError_t launch_set_fingerprints(const MphfDev& m, BvRec* recs_rw, EeRec* ee_rw, const KeyRec* keys, uint64_t n, hipStream_t s) {
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_init_ee, dim3(grid_for(m.nrecs)), dim3(kBlock), 0, s, (const BvRec*)recs_rw, m.nrecs, ee_rw);
-    AIX_LAUNCH(k_set_fp, n, s, m, recs_rw, ee_rw, keys, n);
+hipError_t launch_set_fingerprints(const IndexDev& ix, BvRec* recs_rw, EeRec* ee_rw, bool do_fp, hipStream_t s) {
+    if (ix.n == 0) return hipSuccess;
+    if (ee_rw) hipLaunchKernelGGL(k_init_ee, dim3(grid_for(ix.m.nrecs)), dim3(kBlock), 0, s, (const BvRec*)recs_rw, ix.m.nrecs, ee_rw);
+    AIX_LAUNCH(k_set_fp, ix.n, s, ix, recs_rw, ee_rw, do_fp ? 1 : 0);
 }
 hipError_t launch_build_buckets(const MphfDev& m, const KeyRec* keys, uint64_t n, BkEntry* bk, uint32_t nb, uint32_t* fill, uint64_t* bloom, uint32_t nbloom, uint32_t nbm,
-                                uint32_t* mfill, hipStream_t s) {
+                                uint32_t* mfill, uint32_t* side, hipStream_t s) {
     if (n == 0 || nb == 0) return hipSuccess;
     hipLaunchKernelGGL(k_bk_init, dim3(grid_for((uint64_t)nb * 8)), dim3(kBlock), 0, s, bk, (uint64_t)nb * 8);
-    hipLaunchKernelGGL(k_bk_fill, dim3(grid_for(n)), dim3(kBlock), 0, s, m, keys, n, bk, nb, fill, bloom, nbloom, nbm, mfill);
+    hipLaunchKernelGGL(k_bk_fill, dim3(grid_for(n)), dim3(kBlock), 0, s, m, keys, n, bk, nb, fill, bloom, nbloom, nbm, mfill, side);
     AIX_LAUNCH(k_bk_flag, nb, s, bk, nb, (const uint32_t*)fill);
+}
+hipError_t launch_count_unfiled(const uint32_t* side, uint64_t n, uint32_t* counter, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    AIX_LAUNCH(k_side_count, n, s, side, n, counter);
+}
+hipError_t launch_side_unfiled(const KeyRec* keys, uint64_t n, uint32_t* side, KeyRec* unfiled, uint32_t* counter, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    AIX_LAUNCH(k_side_unfiled, n, s, keys, n, side, unfiled, counter);
 }
 hipError_t launch_fill_minimizer_table(const MphfDev& m, const KeyRec* keys, uint64_t n, BkEntry* mk, const uint32_t* off, uint32_t nbm, uint32_t* mcur, hipStream_t s) {
     if (n == 0 || nbm == 0) return hipSuccess;

@@ -29,9 +29,9 @@ __device__ __forceinline__ bool has_byte(uint64_t x, uint8_t c, uint64_t mask) {
     return (((z - 0x0101010101010101ULL) & ~z) & 0x8080808080808080ULL) != 0;
 }
 
-__global__ void __launch_bounds__(kB) k_tf_u64(const KeyRec* __restrict__ recs, uint64_t n, uint64_t* __restrict__ tf64) {
+__global__ void __launch_bounds__(kB) k_tf_u64(const IndexDev ix, uint64_t n, uint64_t* __restrict__ tf64) {
     const uint64_t stride = (uint64_t)gridDim.x * kB;
-    for (uint64_t i = (uint64_t)blockIdx.x * kB + threadIdx.x; i <= n; i += stride) tf64[i] = i < n ? (uint64_t)recs[i].tf : 0ull;
+    for (uint64_t i = (uint64_t)blockIdx.x * kB + threadIdx.x; i <= n; i += stride) tf64[i] = i < n ? (uint64_t)key_at(ix, i).tf : 0ull;
 }
 
 // bucket of every window (key = n for "no bucket"): hash.cpp:1004-1052. Wave-uniform loop: the verification-table probe is
@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(kB) k_a2_probe(const IndexDev ix, const uint8_
         }
         if (mphf) {
             const uint64_t h = mphf_from_hash(ix.m, a, b, c);
-            if (h < ix.n && ix.keys[h].code == want) key = (uint32_t)h;
+            if (h < ix.n && key_at(ix, h).code == want) key = (uint32_t)h;
         }
         if (in) keys[i] = key;
     }
@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(kB) k_a2_place(const IndexDev ix, const uint32
         const uint32_t h = skeys[j];
         if (h >= n) continue;
         const uint64_t rank = (uint64_t)filled[h] + (j - first[h]);
-        const uint64_t tf = k13 ? ix.tf13_mphf[h] : (uint64_t)ix.keys[h].tf;                       // 13-mer: the u64 table of count_kmers13
+        const uint64_t tf = k13 ? ix.tf13_mphf[h] : (uint64_t)key_at(ix, h).tf;                       // 13-mer: the u64 table of count_kmers13
         if (rank < tf) positions[indices[h] + rank] = piece_first + svals[j] + 1;                // :1037-1040 / compute_aindex13.cpp:205-211, 1-based offsets
     }
 }
@@ -186,7 +186,7 @@ hipError_t positions_indices(const IndexDev& ix, uint64_t* d_indices, hipStream_
     hipError_t e = pool_alloc((void**)&tf64, 8 * (n + 1));
     if (e != hipSuccess) return e;
     if (ix.k == 13) hipLaunchKernelGGL(k_tf13_copy, dim3(grid_of(n + 1)), dim3(kB), 0, s, ix.tf13_mphf, n, tf64);   // compute_aindex13.cpp:57-63
-    else hipLaunchKernelGGL(k_tf_u64, dim3(grid_of(n + 1)), dim3(kB), 0, s, ix.keys, n, tf64);
+    else hipLaunchKernelGGL(k_tf_u64, dim3(grid_of(n + 1)), dim3(kB), 0, s, ix, n, tf64);
     size_t tmp_bytes = 0;
     e = rocprim::exclusive_scan(nullptr, tmp_bytes, tf64, d_indices, (uint64_t)0, (size_t)(n + 1), rocprim::plus<uint64_t>(), s);
     void* tmp = nullptr;

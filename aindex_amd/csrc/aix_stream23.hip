@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(S23_TB) k_stream23_slots(const IndexDev ix, co
             if (need) {
                 uint32_t slot = S23_NONE;
                 if (k.found) slot = k.slot;
-                else if (k.overflow) { const uint64_t h = mphf_from_hash(ix.m, a, b, c); if (h < ix.n && ix.keys[h].code == key) slot = (uint32_t)h; }
+                else if (k.overflow) { const uint64_t h = mphf_from_hash(ix.m, a, b, c); if (h < ix.n && key_at(ix, h).code == key) slot = (uint32_t)h; }
                 v = slot;
             }
         }
@@ -341,7 +341,7 @@ __global__ void __launch_bounds__(S23_TB) k_run23_slots(const IndexDev ix, const
                 ascii23_of_rc(revcomp(key, 23), s0, s1, s2);
                 jenkins23(s0, s1, s2, seed, a, b, c);
                 const uint64_t h = mphf_from_hash(ix.m, a, b, c);
-                v = (h < ix.n && ix.keys[h].code == key) ? (uint32_t)h : S23_NONE;
+                v = (h < ix.n && key_at(ix, h).code == key) ? (uint32_t)h : S23_NONE;
             }
         }
         if (p < nwin) slots[p] = v;
@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(256) k_fix23(const IndexDev ix_, const uint8_t
         jenkins23(s0, s1, s2, ix.m.seed, a, b, c);
         uint32_t slot = S23_NONE;
         const uint64_t h = mphf_from_hash(ix.m, a, b, c);
-        if (h < ix.n && ix.keys[h].code == key) slot = (uint32_t)h;
+        if (h < ix.n && key_at(ix, h).code == key) slot = (uint32_t)h;
         slots[p] = slot;
       }
     }

@@ -612,6 +612,8 @@ def apply_ab_switches(ix, a):
     globals()["_BUCKET_LANES_GIVEN"] = bool(a.bucket_lanes) or bool(os.environ.get("AIX_BUCKET_LANES"))
     if a.no_bucket_table or a.bucket_lanes:
         ix.set_bucket_table(not a.no_bucket_table, a.bucket_lanes)
+    if a.no_bucket_table and not a.no_early_exit:
+        ix.set_early_exit(True)                 # the round-1 walk: its presence masks are built on request since round 3 (2.5 B per key)
     if a.no_absence_filter:
         ix.set_absence_filter(False)
     if a.no_minimizer_table:
