@@ -154,7 +154,7 @@ static void destroy(aix_index* h) {
     if (h->keys) (void)hipFree(h->keys);
     if (h->side) (void)hipFree(h->side);
     if (h->unfiled) (void)hipFree(h->unfiled);
-    if (h->bk) (void)hipFree(h->bk);
+    if (h->bk && !h->bk_borrowed) (void)hipFree(h->bk);
     if (h->bloom) (void)hipFree(h->bloom);
     if (h->mk) (void)hipFree(h->mk);
     if (h->mk_off) (void)hipFree(h->mk_off);
@@ -582,6 +582,36 @@ extern "C" int aix_index_set_bucket_table(aix_index_t* h, int enabled, int lanes
     if (lanes != 0 && lanes != 1 && lanes != 2 && lanes != 4 && lanes != 8) return AIX_ERR_ARG;
     h->bk_enabled = enabled != 0;
     if (lanes) { h->bk_lpp = (uint32_t)lanes; h->bk_lpp_set = true; }
+    return AIX_OK;
+}
+
+// Move the verification table of a 23-mer handle into another block of HBM: d_dst (nb * 128 bytes, caller-owned and kept alive by the caller
+// for the life of the handle) or, with d_dst == NULL, a block allocated now. Placement experiments only (scripts/gpu_r3_relocate.py).
+extern "C" int aix_debug_relocate_table(aix_index_t* h, void* d_dst) {
+    if (!h || h->k != 23 || !h->bk) return AIX_ERR_ARG;
+    DevGuard g(h->device);
+    const uint64_t bytes = (uint64_t)h->nb * 8 * sizeof(BkEntry);
+    BkEntry* nb_ = (BkEntry*)d_dst;
+    if (!nb_) HIPCHK(hipMalloc((void**)&nb_, bytes));
+    HIPCHK(hipMemcpy(nb_, h->bk, bytes, hipMemcpyDeviceToDevice));
+    HIPCHK(hipDeviceSynchronize());
+    if (!h->bk_borrowed) (void)hipFree(h->bk);
+    h->bk = nb_;
+    h->bk_borrowed = d_dst != nullptr;
+    return AIX_OK;
+}
+
+// the same for the absence filter; the old block is NOT freed (the next candidate must come from other physical pages): experiments only
+extern "C" int aix_debug_relocate_bloom(aix_index_t* h, uint64_t pad_bytes) {
+    if (!h || h->k != 23 || !h->bloom) return AIX_ERR_ARG;
+    DevGuard g(h->device);
+    void* pad = nullptr;
+    if (pad_bytes) HIPCHK(hipMalloc(&pad, pad_bytes));               // leaked on purpose: shifts where the next block lands
+    uint64_t* nb_ = nullptr;
+    HIPCHK(hipMalloc((void**)&nb_, 8ull * h->nbloom));
+    HIPCHK(hipMemcpy(nb_, h->bloom, 8ull * h->nbloom, hipMemcpyDeviceToDevice));
+    HIPCHK(hipDeviceSynchronize());
+    h->bloom = nb_;
     return AIX_OK;
 }
 

@@ -64,6 +64,7 @@ struct aix_index {
     uint64_t n_unfiled = 0;
     BkEntry* bk = nullptr;                     // verification table: nb buckets of eight {code, tf, slot} entries (one 128-byte line each)
     uint32_t nb = 0;
+    bool bk_borrowed = false;                  // the table lives in a caller's block (aix_debug_relocate_table)
     uint32_t bk_lpp = 8;                       // lanes that share one bucket read
     bool bk_lpp_set = false;                   // chosen by the caller (AIX_BUCKET_LANES / aix_index_set_bucket_table): then every consumer uses it
     uint64_t bk_unfiled = 0;                   // keys beyond the eighth of their bucket (answered through the MPHF)

@@ -400,6 +400,13 @@ void aix_free(void* p);
 int aix_bench_gather_dev(const void* d_table, uint64_t n_elems, int elem_bytes, int unroll, uint64_t n_access,
                          uint64_t seed, uint64_t* d_sink, void* stream);
 
+/* Diagnostics of the placement experiments (scripts/gpu_r3_relocate.py, gpu_r3_bloomlot.py): move the verification table of a
+ * 23-mer handle into d_dst (nb * 128 bytes, caller-owned, kept alive by the caller) or, with NULL, into a block allocated now; move the
+ * absence filter into a block allocated now (behind `pad_bytes` of padding; the old block and the padding are deliberately not freed, so
+ * that successive moves land on different pages). Answers are unchanged. Not for production use. */
+int aix_debug_relocate_table(aix_index_t* h, void* d_dst);
+int aix_debug_relocate_bloom(aix_index_t* h, uint64_t pad_bytes);
+
 /* self-test hook for the CPU test-suite: the exact-modulo used by the kernels, run on the host */
 uint64_t aix_selftest_mod(uint64_t h, uint64_t d);
 uint64_t aix_selftest_revcomp(uint64_t code, int k);
