@@ -184,8 +184,10 @@ def measure_e2e13(dev, cache, gigabytes, pf13, with_reference=True):
         # (2) the tool, as a process
         exe = os.path.join(ROOT, "bin", "count_kmers13")
         t0 = time.perf_counter()
-        r = subprocess.run([sys.executable, exe, p_plain, pf13, p_out, "16"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=900,
-                           env=dict(os.environ, AIX_TOOL_TIMING="1"))
+        # (a child of a profiled run must not inherit the profiler: its preloaded tool library would attach to the tool as well)
+        child_env = {k: v for k, v in os.environ.items() if not (k == "LD_PRELOAD" or k.startswith(("ROCP", "ROCPROF", "HSA_TOOLS", "ROCTX")))}
+        child_env["AIX_TOOL_TIMING"] = "1"
+        r = subprocess.run([sys.executable, exe, p_plain, pf13, p_out, "16"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=900, env=child_env)
         dt = time.perf_counter() - t0
         res["tool_phases"] = [ln for ln in r.stderr.decode().split("\n") if "timing" in ln][-1:]
         if r.returncode != 0:
@@ -215,7 +217,7 @@ def measure_e2e13(dev, cache, gigabytes, pf13, with_reference=True):
                 o.write(f.read(ns * 151))
             try:
                 t0 = time.perf_counter()
-                subprocess.run([ref, p_s, pf13, p_out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900, check=True)
+                subprocess.run([ref, p_s, pf13, p_out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900, check=True, env=child_env)
                 dtr = time.perf_counter() - t0
                 res["cpu_baseline"] = {"value": ns / dtr, "unit": "reads/s", "cores": os.cpu_count() or 1, "kind": "reference",
                                        "sample": f"first {ns} reads of the same file through oracle/_ref/count_kmers13 (wall clock of the process, its default threads)"}
