@@ -38,7 +38,7 @@ class Info(C.Structure):
                 ("hash_domain", C.c_uint64), ("seed", C.c_uint64), ("bitpairs", C.c_uint64),
                 ("device_bytes", C.c_uint64), ("canonical_only", C.c_uint32), ("bucket_table", C.c_uint32),
                 ("buckets", C.c_uint64), ("bucket_unfiled_keys", C.c_uint64), ("bucket_lanes", C.c_uint32), ("absence_filter_words", C.c_uint32),
-                ("minimizer_lines", C.c_uint64), ("minimizer_unfiled_keys", C.c_uint64), ("count23_backend", C.c_uint32), ("count23_passes", C.c_uint32)]
+                ("minimizer_lines", C.c_uint64), ("minimizer_unfiled_keys", C.c_uint64), ("count23_backend", C.c_uint32), ("count23_passes", C.c_uint32), ("positions_backend", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 class IngestStats(C.Structure):

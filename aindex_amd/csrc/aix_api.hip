@@ -539,6 +539,7 @@ extern "C" int aix_index_info(const aix_index_t* h, aix_info_t* info) {
     info->minimizer_unfiled_keys = h->mk_unfiled;
     info->count23_backend = h->c23_backend;
     info->count23_passes = h->c23_passes;
+    info->positions_backend = h->a2_backend;
     return AIX_OK;
 }
 
@@ -1504,7 +1505,7 @@ extern "C" int aix_positions_fill(aix_index_t* h, const char* reads, uint64_t le
     HIPCHK(dpos.alloc(8 * total));
     HIPCHK(hipMemsetAsync(dpos.p, 0, 8 * total, 0));
     { const int us = upload_host(reads, len, (uint8_t*)dreads.p, h->device); if (us) return us; }
-    POSCHK(positions_fill(h->dev_slots(), (const uint8_t*)dreads.p, len, a2_start(reads, len, h->k), (const uint64_t*)dind.p, (uint64_t*)dpos.p, piece, nullptr, 0, 0));
+    POSCHK(positions_fill(h->dev_slots(), (const uint8_t*)dreads.p, len, a2_start(reads, len, h->k), (const uint64_t*)dind.p, (uint64_t*)dpos.p, piece, nullptr, 0, 0, &h->a2_backend));
     HIPCHK(hipMemcpy(positions_out, dpos.p, 8 * total, hipMemcpyDeviceToHost));
     return AIX_OK;
 }
@@ -1540,7 +1541,7 @@ extern "C" int aix_positions_fill_dev(aix_index_t* h, const char* d_reads, uint6
     if (total == 0) return AIX_OK;
     if (!d_positions_out || positions_cap < total) return AIX_ERR_ARG;
     HIPCHK(hipMemsetAsync(d_positions_out, 0, 8 * total, s));
-    POSCHK(positions_fill(h->dev_slots(), (const uint8_t*)d_reads, len, start, d_indices_out, d_positions_out, piece, nullptr, 0, s));
+    POSCHK(positions_fill(h->dev_slots(), (const uint8_t*)d_reads, len, start, d_indices_out, d_positions_out, piece, nullptr, 0, s, &h->a2_backend));
     return AIX_OK;
 }
 
@@ -1595,7 +1596,7 @@ extern "C" int aix_positions_fill_shard(aix_index_t* h, const char* reads, uint6
     { const int us = upload_host(reads, len, (uint8_t*)dreads.p, h->device); if (us) return us; }
     HIPCHK(hipMemset(dpos.p, 0, 8 * total));
     POSCHK(positions_fill(h->dev_slots(), (const uint8_t*)dreads.p, len, first_shard ? a2_start(reads, len, h->k) : 0, (const uint64_t*)dind.p, (uint64_t*)dpos.p, piece,
-                          filled_init ? (const uint32_t*)dfill.p : nullptr, base_offset, 0));
+                          filled_init ? (const uint32_t*)dfill.p : nullptr, base_offset, 0, &h->a2_backend));
     HIPCHK(hipMemcpy(positions_out, dpos.p, 8 * total, hipMemcpyDeviceToHost));
     return AIX_OK;
 }
@@ -1644,7 +1645,7 @@ extern "C" int aix_positions_fill_shard_dev(aix_index_t* h, const char* d_reads,
     if (h->n == 0) return AIX_OK;
     uint64_t piece = 0;
     if (const char* e = getenv("AIX_POSITIONS_PIECE")) piece = strtoull(e, nullptr, 10);
-    POSCHK(positions_fill(h->dev_slots(), (const uint8_t*)d_reads, len, start, d_indices, d_positions, piece, d_filled_init, base_offset, (hipStream_t)stream));
+    POSCHK(positions_fill(h->dev_slots(), (const uint8_t*)d_reads, len, start, d_indices, d_positions, piece, d_filled_init, base_offset, (hipStream_t)stream, &h->a2_backend));
     return AIX_OK;
 }
 

@@ -122,7 +122,8 @@ hipError_t exclusive_scan_u32(const uint32_t* d_in, uint32_t* d_out, uint64_t n,
 // positions index (aix_positions.hip)
 hipError_t positions_indices(const IndexDev& ix, uint64_t* d_indices /* n+1 */, hipStream_t s);
 hipError_t positions_fill(const IndexDev& ix, const uint8_t* d_reads, uint64_t len, uint64_t start, const uint64_t* d_indices, uint64_t* d_positions,
-                          uint64_t piece, const uint32_t* filled_init, uint64_t base_offset, hipStream_t s);
+                          uint64_t piece, const uint32_t* filled_init, uint64_t base_offset, hipStream_t s,
+                          uint32_t* backend_out = nullptr /* bit 0: a piece went through the stable radix sort, bit 1: through the MSD partition */);
 // grouping of the probe's (bucket, offset) pairs without a full-width sort (aix_a2msd.hip): two-level MSD partition + per-bucket LDS stage
 bool a2_msd_eligible(uint64_t nwin, uint64_t n);
 hipError_t a2_msd_place(const IndexDev& ix, const uint32_t* keys, uint64_t nwin, uint64_t piece_first, uint32_t* filled, bool advance, const uint64_t* d_indices,

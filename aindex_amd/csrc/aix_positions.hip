@@ -222,7 +222,8 @@ hipError_t positions_bucket_counts(const IndexDev& ix, const uint8_t* d_reads, u
 // filled_init (device, u32[n], may be null = zeros): occurrences of every bucket in the shards BEFORE this buffer;
 // base_offset: byte offset of this buffer inside the whole reads file (offsets are reported file-relative).
 hipError_t positions_fill(const IndexDev& ix, const uint8_t* d_reads, uint64_t len, uint64_t start, const uint64_t* d_indices, uint64_t* d_positions,
-                          uint64_t piece, const uint32_t* filled_init, uint64_t base_offset, hipStream_t s) {
+                          uint64_t piece, const uint32_t* filled_init, uint64_t base_offset, hipStream_t s, uint32_t* backend_out) {
+    if (backend_out) *backend_out = 0;
     if (len < ix.k || ix.n == 0) return hipSuccess;
     const uint64_t nwin_all = len - (ix.k - 1);
     if (piece == 0 || piece > (1ull << 31)) piece = 1ull << 30;
@@ -258,10 +259,12 @@ hipError_t positions_fill(const IndexDev& ix, const uint8_t* d_reads, uint64_t l
         if (a2_msd_eligible(nwin, ix.n)) {                                      // grouping by MSD partition + per-bucket LDS stage (aix_a2msd.hip)
             bool untouched = false;
             e = a2_msd_place(ix, keys, nwin, base_offset + w0, filled, more, d_indices, d_positions, s, &untouched);
+            if (e == hipSuccess && backend_out) *backend_out |= 2u;
             if (e == hipSuccess || !untouched) continue;
             (void)hipGetLastError();                                            // its workspace (16 B per window + chunk slack) did not fit: nothing was written,
             e = hipSuccess;                                                     // the sort path below needs about half of that
         }
+        if (backend_out) *backend_out |= 1u;
         if (!skeys) {                                                           // short buffers: one stable radix sort of (bucket, offset)
             e = pool_alloc((void**)&skeys, 4 * pw);
             if (e == hipSuccess) e = pool_alloc((void**)&svals, 4 * pw);

@@ -141,7 +141,7 @@ class Index:
     def info(self) -> dict:
         i = self._info
         check(lib().aix_index_info(self._h, C.byref(i)))
-        return {f: getattr(i, f) for f, _ in i._fields_ if f != "reserved"}
+        return {f: getattr(i, f) for f, _ in i._fields_ if not f.startswith("reserved")}
 
     def set_canonical_fastpath(self, enabled: bool):
         check(lib().aix_index_set_canonical_fastpath(self._h, int(enabled)))

@@ -67,6 +67,9 @@ typedef struct {
     uint32_t count23_backend; /* the last aix_count23_fixed* call on this handle: 0 none yet, 1 memory-side atomics (short buffers,
                                  AIX_COUNT23_ATOMICS=1), 2 slot stream + LDS histogram                                              */
     uint32_t count23_passes;  /* back end 2: passes over the slot stream = ceil(n / 2^26)                                           */
+    uint32_t positions_backend; /* the last aix_positions_fill* call: bit 0 = a piece was grouped by the stable radix sort (short buffers, more than
+                                   2^30 slots, workspace did not fit), bit 1 = by the MSD partition; 0 none yet                    */
+    uint32_t reserved0;
 } aix_info_t;
 
 const char* aix_version(void);

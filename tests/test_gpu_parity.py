@@ -489,6 +489,7 @@ def test_positions_fill_msd_path_equals_sort_path_and_oracle(ix23, gold, small23
         want_ind, want_pos = orc.positions(buf)
         indices, pos = ix.positions_fill(buf)
         assert np.array_equal(indices, want_ind) and np.array_equal(pos, want_pos) and (pos != 0).sum() > 100_000
+        assert ix.info["positions_backend"] == 2                             # which grouping ran is reported, never silent
         os.environ["AIX_POSITIONS_PIECE"] = "70000"
         try:
             indices, pos = ix.positions_fill(buf)
@@ -498,6 +499,7 @@ def test_positions_fill_msd_path_equals_sort_path_and_oracle(ix23, gold, small23
         os.environ["AIX_A2_TEST_NOMEM"] = "1"                              # the MSD workspace "does not fit": the piece takes the sort path, same answer
         try:
             assert np.array_equal(ix.positions_fill(buf)[1], want_pos)
+            assert ix.info["positions_backend"] == 1                         # the sort path, and the handle says so
         finally:
             del os.environ["AIX_A2_TEST_NOMEM"]
         # the shard protocol on top of it (fill counters of earlier shards handed in, file-relative offsets): three shards == the whole
