@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(A2_FB, 6) k_a2_final(const IndexDev ix, const 
     __shared__ uint32_t heavy_n[2];                   // slots of the bucket with more than A2_HEAVY pairs (cleared with hist2)
     __shared__ uint32_t heavy_s[2][A2_CAP / A2_HEAVY];
     const uint32_t t = threadIdx.x, R = 1u << rbits, n = (uint32_t)ix.n;
-    const bool k13 = ix.k == 13;
+
     constexpr int SPT = A2_R / A2_FB;                 // slots a lane owns in the scan
     // A bucket is ~10^3 pairs and its global reads form a chain (bucket bounds -> pairs; slots -> output ranges) of HBM latencies
     // that would dominate the few microseconds of LDS work: everything the NEXT bucket needs from memory is therefore fetched
@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(A2_FB, 6) k_a2_final(const IndexDev ix, const 
                 if (s < R && h < n && n_n) {
                     n_ind[j] = indices[h];
                     n_fl[j] = filled[h];
-                    n_tf[j] = k13 ? ix.tf13_mphf[h] : (uint64_t)key_at(ix, h).tf;
+                    n_tf[j] = indices[h + 1] - n_ind[j];             // tf[h]: indices is its prefix sum (n + 1 entries); no second table is read
                 }
             }
         }
@@ -272,13 +272,13 @@ __global__ void __launch_bounds__(256) k_a2_first64(const uint64_t* __restrict__
 __global__ void __launch_bounds__(256) k_a2_place64(const IndexDev ix, const uint64_t* __restrict__ sorted, uint64_t m, uint64_t piece_first, const uint32_t* __restrict__ first,
                                                    const uint32_t* __restrict__ filled, const uint64_t* __restrict__ indices, uint64_t* __restrict__ positions) {
     const uint64_t stride = (uint64_t)gridDim.x * 256;
-    const bool k13 = ix.k == 13;
+
     for (uint64_t j = (uint64_t)blockIdx.x * 256 + threadIdx.x; j < m; j += stride) {
         const uint64_t e = sorted[j];
         const uint32_t h = (uint32_t)(e >> 32);
         const uint64_t rank = (uint64_t)filled[h] + (j - first[h]);
-        const uint64_t tf = k13 ? ix.tf13_mphf[h] : (uint64_t)key_at(ix, h).tf;
-        if (rank < tf) positions[indices[h] + rank] = piece_first + (uint32_t)e + 1;
+        const uint64_t base = indices[h], tf = indices[h + 1] - base;    // tf[h] from its prefix sums
+        if (rank < tf) positions[base + rank] = piece_first + (uint32_t)e + 1;
     }
 }
 __global__ void __launch_bounds__(256) k_a2_advance64(const uint64_t* __restrict__ sorted, uint64_t m, const uint32_t* __restrict__ first, uint32_t* __restrict__ filled) {

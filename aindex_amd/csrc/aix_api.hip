@@ -1494,7 +1494,7 @@ extern "C" int aix_positions_fill(aix_index_t* h, const char* reads, uint64_t le
     HIPCHK(dind.alloc(8 * (n + 1)));
     if (n) HIPCHK(positions_indices(h->dev(), (uint64_t*)dind.p, 0));
     else HIPCHK(hipMemset(dind.p, 0, 8));
-    HIPCHK(hipMemcpy(indices_out, dind.p, 8 * (n + 1), hipMemcpyDeviceToHost));
+    { const int ds = download_to_host(indices_out, dind.p, 8 * (n + 1), 0); if (ds) return ds; }
     const uint64_t total = indices_out[n];
     if (total_out) *total_out = total;
     if (!positions_out) return AIX_OK;
@@ -1506,7 +1506,7 @@ extern "C" int aix_positions_fill(aix_index_t* h, const char* reads, uint64_t le
     HIPCHK(hipMemsetAsync(dpos.p, 0, 8 * total, 0));
     { const int us = upload_host(reads, len, (uint8_t*)dreads.p, h->device); if (us) return us; }
     POSCHK(positions_fill(h->dev_slots(), (const uint8_t*)dreads.p, len, a2_start(reads, len, h->k), (const uint64_t*)dind.p, (uint64_t*)dpos.p, piece, nullptr, 0, 0, &h->a2_backend));
-    HIPCHK(hipMemcpy(positions_out, dpos.p, 8 * total, hipMemcpyDeviceToHost));
+    { const int ds = download_to_host(positions_out, dpos.p, 8 * total, 0); if (ds) return ds; }
     return AIX_OK;
 }
 
@@ -1568,7 +1568,7 @@ extern "C" int aix_positions_bucket_counts(aix_index_t* h, const char* reads, ui
     { const int us = upload_host(reads, len, (uint8_t*)dreads.p, h->device); if (us) return us; }
     HIPCHK(hipMemset(dcnt.p, 0, 8 * n));
     HIPCHK(positions_bucket_counts(h->dev_slots(), (const uint8_t*)dreads.p, len, first_shard ? a2_start(reads, len, h->k) : 0, (unsigned long long*)dcnt.p, 0));
-    HIPCHK(hipMemcpy(counts_out, dcnt.p, 8 * n, hipMemcpyDeviceToHost));
+    { const int ds = download_to_host(counts_out, dcnt.p, 8 * n, 0); if (ds) return ds; }
     return AIX_OK;
 }
 
@@ -1597,7 +1597,7 @@ extern "C" int aix_positions_fill_shard(aix_index_t* h, const char* reads, uint6
     HIPCHK(hipMemset(dpos.p, 0, 8 * total));
     POSCHK(positions_fill(h->dev_slots(), (const uint8_t*)dreads.p, len, first_shard ? a2_start(reads, len, h->k) : 0, (const uint64_t*)dind.p, (uint64_t*)dpos.p, piece,
                           filled_init ? (const uint32_t*)dfill.p : nullptr, base_offset, 0, &h->a2_backend));
-    HIPCHK(hipMemcpy(positions_out, dpos.p, 8 * total, hipMemcpyDeviceToHost));
+    { const int ds = download_to_host(positions_out, dpos.p, 8 * total, 0); if (ds) return ds; }
     return AIX_OK;
 }
 

@@ -632,6 +632,12 @@ static int download(void* host_dst, OutputFile* of, const void* d_src, uint64_t 
     return st;
 }
 
+// device -> caller memory through the pinned slices (any result of a host-buffer entry point); returns when the bytes are there
+int download_to_host(void* host_dst, const void* d_src, uint64_t bytes, hipStream_t s) {
+    if (bytes == 0) return AIX_OK;
+    return download(host_dst, (OutputFile*)nullptr, d_src, bytes, s, nullptr);
+}
+
 static int count13_any(aix_index_t* h, const ByteSource& src, int format, const char* out_path, uint64_t* tf_out, aix_ingest_stats_t* stats) {
     const double t0 = now_s();
     if (stats) memset(stats, 0, sizeof(*stats));

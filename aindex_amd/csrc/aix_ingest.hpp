@@ -74,6 +74,11 @@ uint64_t ingest_part_bytes();
 void pinned_trim();
 void pinned_warm(int device);
 int upload_pipelined(const ByteSource& src, uint8_t* d_dst, int device, hipStream_t s);
+}  // namespace aix
+// device -> caller memory: 32 MiB slices through two pooled pinned blocks, copied out by the host threads while the next slice is on the link
+// (a pageable destination handed to hipMemcpy is staged by the runtime at a fraction of the link rate); a pinned destination takes one copy
+int download_to_host(void* host_dst, const void* d_src, uint64_t bytes, hipStream_t s);
+namespace aix {
 
 // Consumer side: the source as a sequence of PLAIN parts with the carry in front (see aix_ingest.hip)
 class PlainStream {

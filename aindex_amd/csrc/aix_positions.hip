@@ -94,13 +94,13 @@ __global__ void __launch_bounds__(kB) k_a2_place(const IndexDev ix, const uint32
                                                 const uint64_t* __restrict__ indices, uint64_t* __restrict__ positions) {
     const uint64_t stride = (uint64_t)gridDim.x * kB;
     const uint32_t n = (uint32_t)ix.n;
-    const bool k13 = ix.k == 13;
+
     for (uint64_t j = (uint64_t)blockIdx.x * kB + threadIdx.x; j < nwin; j += stride) {
         const uint32_t h = skeys[j];
         if (h >= n) continue;
         const uint64_t rank = (uint64_t)filled[h] + (j - first[h]);
-        const uint64_t tf = k13 ? ix.tf13_mphf[h] : (uint64_t)key_at(ix, h).tf;                       // 13-mer: the u64 table of count_kmers13
-        if (rank < tf) positions[indices[h] + rank] = piece_first + svals[j] + 1;                // :1037-1040 / compute_aindex13.cpp:205-211, 1-based offsets
+        const uint64_t base = indices[h], tf = indices[h + 1] - base;                             // tf[h] (13-mer: the u64 table of count_kmers13) from its prefix sums
+        if (rank < tf) positions[base + rank] = piece_first + svals[j] + 1;                       // :1037-1040 / compute_aindex13.cpp:205-211, 1-based offsets
     }
 }
 // 13-mer probe (compute_aindex13.cpp:163-204): a window counts iff its 13 bytes are upper-case A/C/G/T; forward strand only;
