@@ -6,6 +6,8 @@
  *                                      The items' character buffers are read by `threads` worker threads (the calling thread keeps the GIL
  *                                      and waits: nothing can mutate or free the items meanwhile, and the workers touch no Python API —
  *                                      they only read the immutable object headers and buffers).
+ *   ascii_view(str)                 -> the characters of an ASCII str as a read-only memoryview (a batch handed over as ONE joined str is
+ *                                      looked up straight from the str's own buffer).
  *   u32_list(buffer, n[, threads])  -> list[int] of the first n uint32 of a buffer. Values <= 256 are CPython's cached small ints: the
  *                                      workers store their addresses straight into the list and tally how often each one was used, the
  *                                      calling thread then adds the tallies to the reference counts; larger values (rare for term
@@ -41,6 +43,11 @@ static void* join_worker(void* p) {
     for (Py_ssize_t i = j->lo; i < j->hi; ++i) {
         PyObject* it = j->items[i];
         const char* src = NULL;
+        if (i + 16 < j->hi) {                           /* the items lie anywhere on the heap: ask for the one 16 ahead now (header and characters: two lines) */
+            const char* nx = (const char*)j->items[i + 16];
+            __builtin_prefetch(nx, 0, 0);
+            __builtin_prefetch(nx + 64, 0, 0);
+        }
         if (PyUnicode_Check(it)) {                      /* macros only: type flags and the compact-ASCII header are read, nothing is called */
             if (PyUnicode_IS_READY(it) && PyUnicode_IS_COMPACT_ASCII(it) && PyUnicode_GET_LENGTH(it) == k) src = (const char*)(((PyASCIIObject*)it) + 1);
         } else if (PyBytes_Check(it)) {
@@ -87,6 +94,15 @@ static PyObject* join_fixed(PyObject* self, PyObject* args) {
     Py_DECREF(fast);
     if (bad) { Py_DECREF(out); Py_RETURN_NONE; }
     return out;
+}
+
+/* ---- ascii_view ------------------------------------------------------------------------------------------------------------ */
+/* ascii_view(s) -> read-only memoryview over the characters of an ASCII str (no copy, no encode pass); None for any other str. The view
+ * borrows the str's own buffer: the caller keeps the str alive while it uses the view. */
+static PyObject* ascii_view(PyObject* self, PyObject* arg) {
+    (void)self;
+    if (!PyUnicode_Check(arg) || PyUnicode_READY(arg) != 0 || !PyUnicode_IS_COMPACT_ASCII(arg)) Py_RETURN_NONE;
+    return PyMemoryView_FromMemory((char*)(((PyASCIIObject*)arg) + 1), PyUnicode_GET_LENGTH(arg), PyBUF_READ);
 }
 
 /* ---- u32_list -------------------------------------------------------------------------------------------------------------- */
@@ -168,6 +184,7 @@ static PyObject* u32_list(PyObject* self, PyObject* args) {
 
 static PyMethodDef methods[] = {
     {"join_fixed", join_fixed, METH_VARARGS, "join_fixed(seq, k[, threads]) -> bytes of len(seq)*k, or None if an item is not a k-character ASCII str / bytes"},
+    {"ascii_view", ascii_view, METH_O, "ascii_view(s) -> read-only memoryview over the characters of an ASCII str, or None"},
     {"u32_list", u32_list, METH_VARARGS, "u32_list(buffer, n[, threads]) -> list[int] of the first n uint32 of the buffer"},
     {NULL, NULL, 0, NULL}};
 

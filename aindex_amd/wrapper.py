@@ -30,7 +30,7 @@ def _enc(s) -> bytes:
 _PYFAST = False
 
 
-_PACK_THREADS = max(1, min(16, (os.cpu_count() or 2) // 2))      # worker threads of the list[str] / list[int] conversions
+_PACK_THREADS = max(1, min(32, (os.cpu_count() or 2) // 2))      # worker threads of the list[str] / list[int] conversions
 
 
 def _pyfast():
@@ -249,9 +249,12 @@ class AindexWrapper:
         if isinstance(kmers, (bytes, bytearray, memoryview)):
             return kmers if len(kmers) % k == 0 else None
         if isinstance(kmers, str):
-            if len(kmers) % k or not kmers.isascii():
+            if len(kmers) % k:
                 return None
-            return kmers.encode("ascii")
+            fast = _pyfast()
+            if fast is not None and hasattr(fast, "ascii_view"):
+                return fast.ascii_view(kmers)                    # the str's own character buffer (None unless it is ASCII); the caller's str outlives the call
+            return kmers.encode("ascii") if kmers.isascii() else None
         if isinstance(kmers, np.ndarray):
             if kmers.dtype.kind == "S" and kmers.dtype.itemsize == k:
                 return np.ascontiguousarray(kmers).view(np.uint8).reshape(-1)
