@@ -118,6 +118,7 @@ SIGNATURES = {
     "aix_dat_load": (i32, [C.c_char_p, i32, C.POINTER(u64), C.POINTER(vp), C.POINTER(vp)]),
     "aix_pf_build_file": (i32, [C.c_char_p, C.POINTER(vp), C.POINTER(u64)]),
     "aix_kmers_write_text": (i32, [C.c_char_p, vp, vp, u64, i32]),
+    "aix_file_write": (i32, [C.c_char_p, vp, u64]),
     "aix_ridx_load": (i32, [C.c_char_p, C.POINTER(u64), C.POINTER(vp)]),
     "aix_normalize_reads_dev": (i32, [vp, u64, i32, i32, vp, C.POINTER(u64), vp]),
     "aix_detect_format": (i32, [vp, u64]),

@@ -22,6 +22,12 @@ from ._lib import check, lib, vp
 from .engine import Index
 
 
+def _write(path, a: np.ndarray):
+    """ndarray -> file through the library's mapped, multi-threaded writer (aix_file_write); the positions image of a few million reads is GBs."""
+    a = np.ascontiguousarray(a)
+    check(lib().aix_file_write(path.encode(), a.ctypes.data_as(vp), a.nbytes), f"aix_file_write({path})")
+
+
 def _mapped(path):
     """The file as a read-only memory map (the library stages it through pinned memory part by part; no host copy is made here)."""
     import os
@@ -115,8 +121,8 @@ def compute_index(argv) -> int:
         print("Conflict!!", file=sys.stderr)
         return 12                                                       # reference: exit(12)
     check(st, "aix_index_scatter")
-    checker.tofile(argv[2] + ".kmers.bin")
-    tf.tofile(argv[2] + ".tf.bin")
+    _write(argv[2] + ".kmers.bin", checker)
+    _write(argv[2] + ".tf.bin", tf)
     return 0
 
 
@@ -159,8 +165,8 @@ def compute_aindex(argv) -> int:
     indices_bin = argv[10] if len(argv) > 10 else prefix + ".indices.bin"
     with Index.open_23(pf, tf_file, kmers_bin) as ix:
         indices, pos = ix.positions_fill(_mapped(reads_file))
-    pos.tofile(index_bin)
-    indices.tofile(indices_bin)
+    _write(index_bin, pos)
+    _write(indices_bin, indices)
     return 0
 
 
@@ -187,8 +193,8 @@ def compute_aindex13(argv) -> int:
             # count_kmers13 misread); `--tf-u32` / AIX_REF_COMPAT=1 indexes exactly that table and so writes the reference's files
             ix.set_tf_13(np.fromfile(tf_file, dtype=np.uint32, count=_lib.TOTAL_13MERS).astype(np.uint64))
         indices, pos = ix.positions_fill(_mapped(reads_file))
-    pos.tofile(index_bin)
-    indices.tofile(indices_bin)
+    _write(index_bin, pos)
+    _write(indices_bin, indices)
     return 0
 
 

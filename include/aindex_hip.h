@@ -362,6 +362,9 @@ int aix_compute_reads(const char* file1, const char* file2 /* nullable */, const
 int aix_dat_load(const char* path, int mock, uint64_t* n_out, char** keys_out, uint32_t** tf_out /* nullable when mock */);
 int aix_pf_build_file(const char* keys_path, void** pf_out, uint64_t* pf_len);
 int aix_kmers_write_text(const char* path, const uint64_t* keys, const uint64_t* counts, uint64_t n, int k);
+/* A binary image to a file (the .index.bin / .indices.bin / .kmers.bin / .tf.bin the tools write: compute_aindex.cpp hash.hpp:470-486,
+ * compute_index.cpp:59-67), through a mapping filled by several host threads. AIX_ERR_IO when the file cannot be created or written. */
+int aix_file_write(const char* path, const void* data, uint64_t bytes);
 /* The .ridx file ("rid\tstart\tend" per read) that compute_reads writes and AindexWrapper::load_reads_index reads back
  * (python_wrapper.cpp:261-279: `fin >> rid >> start >> end` until it fails). *out = 3 * n values, malloc'd (aix_free). */
 int aix_ridx_load(const char* path, uint64_t* n_out, uint64_t** out);

@@ -168,3 +168,17 @@ def test_small_python_helpers():
     assert get_revcomp("ACGTNacgtn~[]") == "[]~nacgtNACGT"
     assert AIndex._index_to_13mer(None, 0) == "A" * 13 and AIndex._index_to_13mer(None, 4 ** 13 - 1) == "T" * 13
     assert AIndex._index_to_13mer(None, 27) == "AAAAAAAAAACGT"
+
+
+def test_file_write_roundtrip(tmp_path):
+    """aix_file_write (host only): the mapped, multi-threaded writer behind the tools' binary images — sizes around its slicing thresholds,
+    empty files, an unwritable path."""
+    import numpy as np
+    L = _lib.lib()
+    rng = np.random.default_rng(3)
+    for n in (0, 1, 4095, 4096, (8 << 20) - 1, (8 << 20) + 5, 40_000_003):
+        a = rng.integers(0, 256, size=n, dtype=np.uint8)
+        p = str(tmp_path / f"f{n}.bin")
+        assert L.aix_file_write(p.encode(), a.ctypes.data_as(_lib.vp) if n else None, n) == 0
+        assert np.array_equal(np.fromfile(p, dtype=np.uint8), a)
+    assert L.aix_file_write(str(tmp_path / "no" / "such" / "dir.bin").encode(), None, 0) == -2
