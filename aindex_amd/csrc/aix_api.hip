@@ -168,6 +168,7 @@ static void destroy(aix_index* h) {
     for (int i = 0; i < 2; ++i) { if (h->probe_ev[i]) (void)hipEventDestroy(h->probe_ev[i]); if (h->hist_ev[i]) (void)hipEventDestroy(h->hist_ev[i]); }
     if (h->start_ev) (void)hipEventDestroy(h->start_ev);
     if (h->probe_stream) (void)hipStreamDestroy(h->probe_stream);
+    if (h->hist_stream) (void)hipStreamDestroy(h->hist_stream);
     if (h->small_stream) (void)hipStreamDestroy(h->small_stream);
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_cov) (void)hipHostFree(h->pin_cov);
@@ -911,11 +912,26 @@ extern "C" int aix_count23_fixed_dev(aix_index_t* h, const char* d_plain, uint64
     struct ProbeDrainOnError {
         aix_index* h;
         bool armed = true;
-        ~ProbeDrainOnError() { if (armed && h->probe_stream) (void)hipStreamSynchronize(h->probe_stream); }
+        ~ProbeDrainOnError() { if (armed && h->probe_stream) (void)hipStreamSynchronize(h->probe_stream); if (armed && h->hist_stream) (void)hipStreamSynchronize(h->hist_stream); }
     } probe_drain{h};
     HIPCHK(hipMemsetAsync(h->work13, 0, 4, s));                               // the error word of the partition workspace
+    // AIX_COUNT23_HIST_CUS=n[,style] (A/B switch, read when the streams are first made): the partition + histogram kernels get n of the 256 CUs
+    // and the probe the others, through CU-masked streams. The split kernel takes a whole CU (152 KiB of LDS, 16 waves of 128 VGPRs), so on
+    // shared CUs the two kernels alternate workgroup by workgroup instead of running side by side. style 0: the low n bits of the mask, 1: every
+    // (256 / n)-th bit.
+    hipStream_t hs = s;
     if (overlap) {
         if (!h->probe_stream) {
+            int hist_cus = 0, style = 0;
+            if (const char* e = getenv("AIX_COUNT23_HIST_CUS")) { hist_cus = atoi(e); if (const char* c = strchr(e, ',')) style = atoi(c + 1); }
+            if (hist_cus >= 8 && hist_cus <= 224) {
+                uint32_t mh[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mp[8];
+                const int step = style ? 256 / hist_cus : 1;
+                for (int i = 0, c = 0; c < hist_cus && i < 256; i += step, ++c) mh[i >> 5] |= 1u << (i & 31);
+                for (int w = 0; w < 8; ++w) mp[w] = ~mh[w];
+                HIPCHK(hipExtStreamCreateWithCUMask(&h->probe_stream, 8, mp));
+                HIPCHK(hipExtStreamCreateWithCUMask(&h->hist_stream, 8, mh));
+            } else
             HIPCHK(hipStreamCreateWithFlags(&h->probe_stream, hipStreamNonBlocking));
             for (int i = 0; i < 2; ++i) {
                 HIPCHK(hipEventCreateWithFlags(&h->probe_ev[i], hipEventDisableTiming));
@@ -925,6 +941,7 @@ extern "C" int aix_count23_fixed_dev(aix_index_t* h, const char* d_plain, uint64
         }
         HIPCHK(hipEventRecord(h->start_ev, s));                                // the reads (and whatever else the caller queued) are ready when the first probe starts
         HIPCHK(hipStreamWaitEvent(h->probe_stream, h->start_ev, 0));
+        if (h->hist_stream) { hs = h->hist_stream; HIPCHK(hipStreamWaitEvent(hs, h->start_ev, 0)); }
     }
     // the slot-stream probe of the counter runs best with two lanes per bucket line (38.7-40.4 against 42.5-42.7 ms per 10 M reads with
     // eight, same box): nothing but the 4-byte slot leaves the kernel, so fewer, wider reads per probe win; lookups keep eight
@@ -948,15 +965,16 @@ extern "C" int aix_count23_fixed_dev(aix_index_t* h, const char* d_plain, uint64
             if (ip >= 2) HIPCHK(hipStreamWaitEvent(h->probe_stream, h->hist_ev[b], 0));      // piece ip - 2 has been read out of this buffer
             HIPCHK(probe((const uint8_t*)d_plain + first, w + 22, slots, h->probe_stream));
             HIPCHK(hipEventRecord(h->probe_ev[b], h->probe_stream));
-            HIPCHK(hipStreamWaitEvent(s, h->probe_ev[b], 0));
+            HIPCHK(hipStreamWaitEvent(hs, h->probe_ev[b], 0));
         } else {
             HIPCHK(probe((const uint8_t*)d_plain + first, w + 22, slots, s));
         }
         uint32_t passes = 0;
-        HIPCHK(launch_histogram_slots(slots, w, h->work13, d_tf_out, h->n, s, range_bits, &passes));
+        HIPCHK(launch_histogram_slots(slots, w, h->work13, d_tf_out, h->n, hs, range_bits, &passes));
         h->c23_backend = 2; h->c23_passes = passes;
-        if (overlap) HIPCHK(hipEventRecord(h->hist_ev[ip & 1], s));
+        if (overlap) HIPCHK(hipEventRecord(h->hist_ev[ip & 1], hs));
     }
+    if (hs != s && ip) HIPCHK(hipStreamWaitEvent(s, h->hist_ev[(ip - 1) & 1], 0));
     uint32_t dropped = 0;
     HIPCHK(hipMemcpyAsync(&dropped, h->work13, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));

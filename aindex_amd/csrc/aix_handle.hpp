@@ -94,6 +94,7 @@ struct aix_index {
     struct HostPipe* pipe = nullptr;           // pinned staging + streams of the large host-buffer batches (lazily built)
     std::mutex pipe_mutex;
     hipEvent_t work13_done = nullptr;          // recorded behind every counting call: the next one (any stream) waits for it before touching the workspace
+    hipStream_t hist_stream = nullptr;         // count23, AIX_COUNT23_HIST_CUS only: the partition + histogram kernels on their own CUs (CU-masked stream)
     hipStream_t probe_stream = nullptr;        // count23: the slot probe of piece i + 1 runs here while piece i is partitioned and added on the caller's stream
     hipEvent_t probe_ev[2] = {nullptr, nullptr}, hist_ev[2] = {nullptr, nullptr}, start_ev = nullptr;
     uint64_t device_bytes = 0;
