@@ -416,7 +416,9 @@ __global__ void __launch_bounds__(kBlock) k_coverage(const IndexDev ix_, const u
         // sequence containing byte p: largest s with offs[s] <= p. The lanes of a wave hold consecutive p, so the binary search
         // runs once per wave for its first position (wave-uniform: scalar loads), and a lane then walks forward from there —
         // zero or one step unless the sequences are shorter than a wave is wide (then a bounded walk, then its own search).
-        const uint64_t p0 = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(p_base >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)p_base);
+        // (the builtin returns int: without the cast a low half with bit 31 set sign-extends over the high half, the search lands on the last
+        // sequence and the positions [2^31, 2^32) mod 2^32 of a batch come back 0 — rounds 1 and 2 did that to 43 % of config 5 at full size)
+        const uint64_t p0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(p_base >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)p_base);
         uint64_t lo = 0, hi = M;                                // invariant offs[lo] <= p0 < offs[hi] (or lo == 0)
         while (hi - lo > 1) {
             const uint64_t mid = (lo + hi) >> 1;

@@ -107,6 +107,21 @@ def timed_steps(step_fn, steps, warmup, device, collective=True):
     return wall, float(np.mean(kern_ms)), kern_ms
 
 
+def clean_windows(reads_t, n_reads, read_len, k):
+    """Windows of k bases without an 'N' in a buffer of fixed-length records, counted with torch in slabs (independent of the library):
+    what sum(counts) of a counting workload must equal when the reads are drawn from ACGT genomes with sprinkled Ns."""
+    import torch
+    rows = reads_t.view(n_reads, read_len + 1)
+    total = 0
+    for lo in range(0, n_reads, 5_000_000):
+        is_n = (rows[lo:lo + 5_000_000, :read_len] == ord("N")).to(torch.int16)
+        c = torch.cumsum(is_n, dim=1)
+        inside = c[:, k - 1:] - torch.cat([torch.zeros(c.shape[0], 1, dtype=torch.int16, device=c.device), c[:, :-k]], dim=1)
+        total += int((inside == 0).sum().item())
+        del is_n, c, inside
+    return total
+
+
 def scratch_dir(need_bytes, cache):
     """Where the end-to-end workloads put their input files: /dev/shm (page-cache speed: the measurement is the pipeline, not a disk)
     when it has the room, else the bench cache directory."""
@@ -700,9 +715,15 @@ def measure_count23_strong(ix, g, rank, world, dev, total_reads, steps, warmup):
         del scratch
     # kernel alone on this rank's share (no zeroing, no collective): the figure the roofline object is built from
     k_only, k_ms, _ = timed_steps(lambda: ix.count23_fixed_t(reads, _lib.CANON_TRUE_RC, tf), 2, 0, dev)
+    # every window without N of every rank's reads is a key of the index (genome reads), so the merged histogram must sum to their number,
+    # counted independently with torch on each rank's own reads
+    clean = torch.tensor([clean_windows(reads, hi - lo, 150, 23)], dtype=torch.int64, device=reads.device)
     del reads
     import torch.distributed as dist
     backend = dist.get_backend() if (dist.is_available() and dist.is_initialized()) else "none"
+    adist.all_reduce_sum_(clean)
+    if int(clean.item()) != digest["sum"]:
+        raise SystemExit(f"count23_strong: sum(tf) = {digest['sum']}, windows without N = {int(clean.item())}")
     windows_rank = (hi - lo) * (150 - 22)
     # N > 1: rank 0 then runs the WHOLE workload alone (same reads, same kernel, no collective) — the 1-GPU rate of this very
     # metric measured in the same process, and the histogram the sharded + all-reduced one must equal (digest of all tf[] entries)
@@ -731,7 +752,7 @@ def measure_count23_strong(ix, g, rank, world, dev, total_reads, steps, warmup):
             "kernel": "k_count23_fixed", "kernel_ms_this_rank": k_ms, "windows_this_rank": windows_rank,
             "counting_backend": {1: "memory-side atomics", 2: "slot stream + LDS histogram"}.get(ix.info["count23_backend"], "none"),
             "histogram_passes": ix.info["count23_passes"],
-            "windows_counted_all_ranks": digest["sum"], "tf_digest": digest,
+            "windows_counted_all_ranks": digest["sum"], "windows_without_N_all_ranks": int(clean.item()), "tf_digest": digest,
             "one_device_rehearsal": bool(os.environ.get("AIX_BENCH_ONE_DEVICE"))}
 
 
@@ -1057,6 +1078,9 @@ def main():
         step = lambda: ix.coverage_t(seqs, offs, ooffs, a.seqs * per, 0, outp)
         wall, kern_ms, _ = timed_steps(step, a.steps, a.warmup, dev)
         positions = a.seqs * per
+        nzf = int(torch.count_nonzero(outp).item()) / outp.numel()
+        if nzf < 0.97:                                              # windows without N are keys: (1 - 0.001)^23 = 0.977; a line over a wrong profile is not a measurement
+            raise SystemExit(f"coverage23: only {nzf:.4f} of the positions came back non-zero (expected ~0.98)")
         pp = ix.probe_profile()
         achieved = positions * (1.0 + pp["bytes_per_hit_probe"] + 4.0) / (kern_ms * 1e-3) / 1e9     # 1 B of sequence + one probe + the 4-byte answer per position
         cb = None
@@ -1065,7 +1089,7 @@ def main():
         out.update({"metric": "sequences_per_sec_coverage_23mer", "value": world * a.seqs * a.steps / wall, "unit": "sequences/s",
                     "ms_per_step": wall / a.steps * 1e3, "dtype": "u64",
                     "config": {"workload": f"configs[4]: per-position tf profile (k=23) of {L} bp sequences drawn from the indexed genome (50 % rc, 0.1 % N)",
-                               "sequences_per_step_per_gpu": a.seqs, "positions_per_step": positions, "nonzero_fraction": int(torch.count_nonzero(outp).item()) / outp.numel()},
+                               "sequences_per_step_per_gpu": a.seqs, "positions_per_step": positions, "nonzero_fraction": nzf},
                     **({"cpu_baseline": cb} if cb else {}),
                     "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                  "traffic": None, "kernel": "k_coverage", "kernel_ms": kern_ms, "positions_per_sec": positions / (kern_ms * 1e-3),
@@ -1100,11 +1124,14 @@ def main():
         step = lambda: ix.coverage_t(seqs, offs, ooffs, a.seqs * per, 0, outp)
         wall, kern_ms, _ = timed_steps(step, a.steps, a.warmup, dev)
         positions = a.seqs * per
+        nzf13 = int(torch.count_nonzero(outp).item()) / outp.numel()
+        if nzf13 < 0.97:                                            # forward reads of the counted genome: every window without N has a count
+            raise SystemExit(f"coverage13: only {nzf13:.4f} of the positions came back non-zero (expected ~0.99)")
         achieved = positions * (1.0 + 8.0 + 4.0) / (kern_ms * 1e-3) / 1e9      # one 8-byte read of the code-ordered table per position
         out.update({"metric": "sequences_per_sec_coverage_13mer", "value": world * a.seqs * a.steps / wall, "unit": "sequences/s",
                     "ms_per_step": wall / a.steps * 1e3, "dtype": "u64",
                     "config": {"workload": f"configs[4]: per-position tf profile (k=13) of {L} bp sequences drawn from the counted genome (0.1 % N)",
-                               "sequences_per_step_per_gpu": a.seqs, "positions_per_step": positions, "nonzero_fraction": int(torch.count_nonzero(outp).item()) / outp.numel()},
+                               "sequences_per_step_per_gpu": a.seqs, "positions_per_step": positions, "nonzero_fraction": nzf13},
                     "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                  "traffic": None, "kernel": "k_coverage", "kernel_ms": kern_ms, "positions_per_sec": positions / (kern_ms * 1e-3)}})
 
@@ -1117,6 +1144,9 @@ def main():
         wall, kern_ms, _ = timed_steps(step, a.steps, a.warmup, dev)
         keys_t, counts_t = res["o"]
         windows = a.reads * (150 - 22)
+        counted, clean = int(counts_t.to(torch.int64).sum().item()), clean_windows(reads, a.reads, 150, 23)
+        if counted != clean:                                        # every window without N is counted exactly once, whatever the number of pieces merged
+            raise SystemExit(f"distinct23: sum(counts) = {counted}, windows without N = {clean}")
         msd = os.environ.get("AIX_K1_ROCPRIM") is None
         positions_n = a.reads * 151 - 22
         distinct_n = int(keys_t.numel())
@@ -1134,7 +1164,8 @@ def main():
         out.update({"metric": "reads_per_sec_23mer_distinct_count", "value": world * a.reads * a.steps / wall, "unit": "reads/s",
                     "ms_per_step": wall / a.steps * 1e3, "dtype": "u64",
                     "config": {"workload": "K1 (kmer_counter): distinct canonical 23-mers of 150 bp reads with their counts, reads resident in HBM, per-rank sets (no exchange)",
-                               "reads_per_step_per_gpu": a.reads, "windows": windows, "distinct_kmers": int(keys_t.numel())},
+                               "reads_per_step_per_gpu": a.reads, "windows": windows, "distinct_kmers": int(keys_t.numel()), "sum_counts": counted,
+                               "sum_counts_check": "equals the windows without N counted independently with torch"},
                     **({"cpu_baseline": cb.get("reference", cb["port_1t"]), "cpu_baseline_extra": cb} if cb else {}),
                     "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                                  "kernel": ("k_window_codes + k_k1_split / k_k1_count / k_k1_scatter / k_k1_final / k_k1_gather (aix_count_distinct_dev)" if msd
