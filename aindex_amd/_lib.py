@@ -142,6 +142,8 @@ SIGNATURES = {
     "aix_pf_build_all_13mers": (i32, [C.POINTER(vp), C.POINTER(u64)]),
     "aix_free": (None, [vp]),
     "aix_scratch_trim": (None, []),
+    "aix_host_alloc": (i32, [u64, C.POINTER(vp)]),
+    "aix_host_free": (i32, [vp]),
     "aix_debug_relocate_table": (i32, [vp, vp]),
     "aix_debug_relocate_bloom": (i32, [vp, u64]),
     "aix_selftest_mod": (u64, [u64, u64]),

@@ -60,6 +60,23 @@ extern "C" int aix_device_count(int* count) {
 
 extern "C" void aix_scratch_trim(void) { pool_trim(); pinned_trim(); }
 
+extern "C" int aix_host_alloc(uint64_t bytes, void** out) {
+    if (!out) return AIX_ERR_ARG;
+    *out = nullptr;
+    if (bytes == 0) return AIX_OK;
+    void* p = nullptr;
+    const hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); set_last_error("aix_host_alloc: out of pinned memory"); return AIX_ERR_NOMEM; }
+    HIPCHK(e);
+    *out = p;
+    return AIX_OK;
+}
+extern "C" int aix_host_free(void* p) {
+    if (!p) return AIX_OK;
+    HIPCHK(hipHostFree(p));
+    return AIX_OK;
+}
+
 extern "C" uint64_t aix_selftest_mod(uint64_t h, uint64_t d) { return fastmod(h, make_fastmod(d)); }
 extern "C" uint64_t aix_selftest_revcomp(uint64_t code, int k) { return revcomp(code, k); }
 

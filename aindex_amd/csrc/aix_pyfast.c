@@ -6,6 +6,7 @@
  *                                      The items' character buffers are read by `threads` worker threads (the calling thread keeps the GIL
  *                                      and waits: nothing can mutate or free the items meanwhile, and the workers touch no Python API —
  *                                      they only read the immutable object headers and buffers).
+ *   join_fixed_into(seq, k, buf[, threads]) -> the same into a caller's writable buffer (the wrapper's pinned staging, kept between calls).
  *   ascii_view(str)                 -> the characters of an ASCII str as a read-only memoryview (a batch handed over as ONE joined str is
  *                                      looked up straight from the str's own buffer).
  *   u32_list(buffer, n[, threads])  -> list[int] of the first n uint32 of a buffer. Values <= 256 are CPython's cached small ints: the
@@ -96,6 +97,48 @@ static PyObject* join_fixed(PyObject* self, PyObject* args) {
     return out;
 }
 
+/* join_fixed_into(seq, k, buffer[, threads]) -> True, or None when an item is not a k-character ASCII str / k-byte bytes (buffer contents
+ * then undefined). `buffer` is a writable buffer of at least len(seq) * k bytes — the wrapper's pinned staging, written in place. */
+static PyObject* join_fixed_into(PyObject* self, PyObject* args) {
+    PyObject* seq;
+    Py_ssize_t k;
+    Py_buffer view;
+    long threads = 0;
+    (void)self;
+    if (!PyArg_ParseTuple(args, "Onw*|l", &seq, &k, &view, &threads)) return NULL;
+    if (k <= 0) { PyBuffer_Release(&view); Py_RETURN_NONE; }
+    PyObject* fast = PySequence_Fast(seq, "join_fixed_into: expected a sequence");
+    if (!fast) { PyBuffer_Release(&view); return NULL; }
+    const Py_ssize_t n = PySequence_Fast_GET_SIZE(fast);
+    if (n > PY_SSIZE_T_MAX / k || view.len < n * k) {
+        Py_DECREF(fast); PyBuffer_Release(&view);
+        PyErr_SetString(PyExc_ValueError, "join_fixed_into: buffer shorter than len(seq) * k bytes");
+        return NULL;
+    }
+    const int nt = pick_threads(n, threads);
+    join_job jobs[MAX_THREADS];
+    pthread_t th[MAX_THREADS];
+    int started[MAX_THREADS];
+    PyObject** items = PySequence_Fast_ITEMS(fast);
+    for (int t = 0; t < nt; ++t) {
+        jobs[t].items = items; jobs[t].k = k; jobs[t].dst = (char*)view.buf; jobs[t].bad = 0;
+        jobs[t].lo = n / nt * t + (t < n % nt ? t : n % nt);
+        jobs[t].hi = jobs[t].lo + n / nt + (t < n % nt ? 1 : 0);
+        started[t] = 0;
+    }
+    for (int t = 1; t < nt; ++t) started[t] = pthread_create(&th[t], NULL, join_worker, &jobs[t]) == 0;      /* GIL held by this thread throughout, as in join_fixed */
+    join_worker(&jobs[0]);
+    int bad = jobs[0].bad;
+    for (int t = 1; t < nt; ++t) {
+        if (started[t]) pthread_join(th[t], NULL); else join_worker(&jobs[t]);
+        bad |= jobs[t].bad;
+    }
+    Py_DECREF(fast);
+    PyBuffer_Release(&view);
+    if (bad) Py_RETURN_NONE;
+    Py_RETURN_TRUE;
+}
+
 /* ---- ascii_view ------------------------------------------------------------------------------------------------------------ */
 /* ascii_view(s) -> read-only memoryview over the characters of an ASCII str (no copy, no encode pass); None for any other str. The view
  * borrows the str's own buffer: the caller keeps the str alive while it uses the view. */
@@ -184,6 +227,7 @@ static PyObject* u32_list(PyObject* self, PyObject* args) {
 
 static PyMethodDef methods[] = {
     {"join_fixed", join_fixed, METH_VARARGS, "join_fixed(seq, k[, threads]) -> bytes of len(seq)*k, or None if an item is not a k-character ASCII str / bytes"},
+    {"join_fixed_into", join_fixed_into, METH_VARARGS, "join_fixed_into(seq, k, buffer[, threads]) -> True, or None if an item is not a k-character ASCII str / bytes"},
     {"ascii_view", ascii_view, METH_O, "ascii_view(s) -> read-only memoryview over the characters of an ASCII str, or None"},
     {"u32_list", u32_list, METH_VARARGS, "u32_list(buffer, n[, threads]) -> list[int] of the first n uint32 of the buffer"},
     {NULL, NULL, 0, NULL}};

@@ -198,6 +198,12 @@ class Index:
         check(lib().aix_tf_batch_ascii(self._h, _np_ptr(a), n, _np_ptr(out)), "aix_tf_batch_ascii")
         return out
 
+    def tf_ascii_into(self, a: np.ndarray, out: np.ndarray) -> np.ndarray:
+        """tf_ascii on caller-owned buffers (contiguous uint8[n*k] in, uint32[n] out) — e.g. pinned staging kept between calls."""
+        assert a.dtype == np.uint8 and out.dtype == np.uint32 and a.flags.c_contiguous and out.flags.c_contiguous and a.shape[0] == out.shape[0] * self.k
+        check(lib().aix_tf_batch_ascii(self._h, _np_ptr(a), out.shape[0], _np_ptr(out)), "aix_tf_batch_ascii")
+        return out
+
     def tf_codes(self, codes: np.ndarray) -> np.ndarray:
         c = np.ascontiguousarray(codes, dtype=np.uint64)
         out = np.empty(c.shape[0], dtype=np.uint32)

@@ -51,9 +51,55 @@ def _pyfast():
     return _PYFAST
 
 
+class _Stage:
+    """Pinned staging of the list surface, kept between calls: the packed query bytes on the way in, the uint32 answers on the way out
+    (aix_host_alloc). A fresh 460 MB bytes object per call is page-faulted by the packing threads — that cost more than the packing and the
+    lookup together — and pageable buffers cross the link at 2/3 of the pinned rate. Blocks grow geometrically; above AIX_STAGE_MAX_MB
+    (default 4096) per direction, or while another thread is inside, the caller takes the unstaged path. Answers never depend on it."""
+
+    def __init__(self):
+        import threading
+        self.lock = threading.Lock()
+        self._blk = {}                                     # name -> (pointer, capacity in bytes, uint8 array over it)
+        self._max = int(os.environ.get("AIX_STAGE_MAX_MB", "4096")) << 20
+
+    def view(self, name: str, nbytes: int):
+        """uint8 array of at least nbytes pinned bytes (the caller holds self.lock), or None."""
+        import ctypes as C
+        blk = self._blk.get(name)
+        if blk is not None and blk[1] >= nbytes:
+            return blk[2]
+        if nbytes > self._max:
+            return None
+        cap = min(self._max, max(nbytes + nbytes // 2, 1 << 24))
+        lib = _lib.lib()
+        if blk is not None:
+            del self._blk[name]
+            lib.aix_host_free(blk[0])
+        p = C.c_void_p()
+        if lib.aix_host_alloc(cap, C.byref(p)) != 0 or not p.value:
+            return None
+        arr = np.ctypeslib.as_array((C.c_uint8 * cap).from_address(p.value))
+        self._blk[name] = (p, cap, arr)
+        return arr
+
+    def close(self):
+        with self.lock:
+            blks, self._blk = self._blk, {}
+        for p, _, _ in blks.values():
+            _lib.lib().aix_host_free(p)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                                  # noqa: BLE001 — interpreter shutdown
+            pass
+
+
 class AindexWrapper:
     def __init__(self, device: int = 0):
         self._device = device
+        self._stage = _Stage()
         self._ix23: Optional[Index] = None
         self._ix13: Optional[Index] = None
         self._is_13mer_mode = False
@@ -291,9 +337,34 @@ class AindexWrapper:
             return None
         return flat
 
+    def _tf_list_staged(self, ix: Index, kmers, k: int):
+        """list of k-character items -> list[int] through the pinned staging (packing threads write the query bytes straight into it, the
+        answers come back into it); None when this batch has to take the general path (helper missing, an odd item, staging busy or too small)."""
+        fast = _pyfast()
+        if fast is None or not hasattr(fast, "join_fixed_into") or not isinstance(kmers, (list, tuple)) or len(kmers) < 4096:
+            return None
+        st = self._stage
+        if not st.lock.acquire(blocking=False):
+            return None
+        try:
+            n = len(kmers)
+            qin, aout = st.view("in", n * k), st.view("out", 4 * n)
+            if qin is None or aout is None:
+                return None
+            if fast.join_fixed_into(kmers, k, qin, _PACK_THREADS) is None:
+                return None
+            out = aout[: 4 * n].view(np.uint32)
+            ix.tf_ascii_into(qin[: n * k], out)
+            return fast.u32_list(out, n, _PACK_THREADS)
+        finally:
+            st.lock.release()
+
     def get_tf_values_23mer(self, kmers: List[str]) -> List[int]:
         if len(kmers) == 0:
             return []
+        staged = self._tf_list_staged(self._need23(), kmers, 23)
+        if staged is not None:
+            return staged
         flat = self._packed(kmers, 23)                                                  # one buffer of N*23 bytes: nothing to do per item
         if flat is None and not isinstance(kmers, (str, bytes, bytearray, memoryview, np.ndarray)):
             flat = self._join_fixed(kmers, 23)                                          # common case: a list of 23-mers
@@ -312,6 +383,9 @@ class AindexWrapper:
             return [0] * len(kmers)
         if len(kmers) == 0:
             return []
+        staged = self._tf_list_staged(self._ix13, kmers, 13)
+        if staged is not None:
+            return staged
         flat = self._packed(kmers, 13)
         if flat is None and not isinstance(kmers, (str, bytes, bytearray, memoryview, np.ndarray)):
             flat = self._join_fixed(kmers, 13)
@@ -573,3 +647,4 @@ class AindexWrapper:
             if ix is not None:
                 ix.close()
         self._ix23 = self._ix13 = None
+        self._stage.close()

@@ -79,6 +79,12 @@ int aix_device_count(int* count);
  * blocks (a hipMalloc of that size costs ~20 ms). AIX_SCRATCH_CACHE_GB (default 40) bounds the cache; this and
  * aix_index_close() return it to the driver. */
 void aix_scratch_trim(void);                     /* AIX_ERR_HIP if the runtime is unusable  */
+/* Page-locked host memory for the buffers a binding hands to the host-pointer entry points (queries in, answers out): a pinned buffer
+ * crosses the link at ~48 GB/s instead of ~32 GB/s through the library's own staging, and one kept between calls is not page-faulted again
+ * (a fresh 460 MB buffer written by 32 threads costs more than the lookup it feeds). This is where the reference's binding holds the
+ * std::vector<std::string> / std::vector<uint32_t> of get_tf_values (python_wrapper.cpp:653-664). Free with aix_host_free only. */
+int aix_host_alloc(uint64_t bytes, void** out);
+int aix_host_free(void* p);
 
 /* ------------------------------------------------------------------------------------------
  * Index lifecycle.

@@ -634,6 +634,18 @@ def test_python_mirrors(gold, small23_prefix, tmp_path):
     assert w.get_tf_values(fixed[0]) == [want[0]] and w.get_tf_values(fixed[0][:20]) == [0] and w.get_tf_values([]) == [] and w.get_tf_values("") == []
     big = fixed * (250_000 // len(fixed) + 1)
     assert w.get_tf_values(big) == want * (250_000 // len(fixed) + 1)
+    # lists of >= 4096 items go through the wrapper's pinned staging (kept between calls, grown when a larger batch arrives); a busy staging,
+    # an odd item or a batch above AIX_STAGE_MAX_MB falls back to the unstaged path with the same answers
+    reps = 250_000 // len(fixed) + 1
+    assert w._stage._blk and w.get_tf_values(tuple(big)) == want * reps                 # second call: same blocks
+    cap_before = w._stage._blk["in"][1]
+    assert w.get_tf_values(big * 3) == want * (3 * reps) and w._stage._blk["in"][1] > cap_before
+    with w._stage.lock:
+        assert w.get_tf_values(big) == want * reps                                      # staging busy (another thread inside): unstaged path
+    odd = list(big)
+    odd[1234] = fixed[0][:20]                                                           # one 20-character item: the general (ragged) path answers 0 for it
+    got = w.get_tf_values(odd)
+    assert got[1234] == 0 and got[:1234] == (want * reps)[:1234] and got[1235:] == (want * reps)[1235:]
     from aindex_amd.wrapper import AindexWrapper as _W
     vals = np.array([0, 1, 255, 256, 257, 65536, 2 ** 32 - 1] * 40_000, dtype=np.uint32)
     lst = _W._to_list(vals)

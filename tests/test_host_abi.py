@@ -143,6 +143,28 @@ def test_list_packing_helper_matches_python_rules():
             wrapper._PYFAST = saved
 
 
+def test_list_packing_into_a_callers_buffer():
+    """join_fixed_into (the wrapper's pinned staging is such a buffer): same bytes as join_fixed, None for an odd item, an error for a short buffer."""
+    from aindex_amd import wrapper
+    fast = wrapper._pyfast()
+    if fast is None:
+        pytest.skip("aix_pyfast not built")
+    rng = np.random.default_rng(9)
+    items = ["".join(rng.choice(list("ACGTN"), size=23)) for _ in range(1000)] * 300     # 300 000 items: above the helper's thread threshold
+    items[7] = items[7].encode()
+    buf = np.zeros(len(items) * 23 + 5, dtype=np.uint8)
+    assert fast.join_fixed_into(items, 23, buf, 8) is True
+    assert buf[: len(items) * 23].tobytes() == fast.join_fixed(items, 23, 8) and not buf[len(items) * 23:].any()
+    assert fast.join_fixed_into(tuple(items[:10]), 23, buf) is True and fast.join_fixed_into([], 23, buf) is True
+    bad = list(items)
+    bad[250_000] = "ACG"
+    assert fast.join_fixed_into(bad, 23, buf, 8) is None and fast.join_fixed_into(["ACGTACGTACGTACGTACGTAC€"], 23, buf) is None
+    with pytest.raises(ValueError):
+        fast.join_fixed_into(items, 23, np.zeros(100, dtype=np.uint8))
+    with pytest.raises((TypeError, BufferError, ValueError)):
+        fast.join_fixed_into(items[:4], 23, bytes(200))                                 # read-only buffer
+
+
 def test_read_interval_bisection_equals_linear_rule():
     """get_rid / get_start: the bisection used for sorted, disjoint .ridx intervals returns what the reference's linear scan
     (first interval with start <= pos + 1 and end + 1 >= pos, python_wrapper.cpp:66-74) returns, gaps and touching reads included."""
