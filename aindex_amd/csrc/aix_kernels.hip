@@ -408,7 +408,8 @@ __global__ void __launch_bounds__(kBlock) k_lookup13_ragged(const IndexDev ix, c
 // ---------------------------------------------------------------------------------------------
 template <bool CANON, int LPP>
 __global__ void __launch_bounds__(kBlock) k_coverage(const IndexDev ix_, const uint8_t* __restrict__ seqs, const uint64_t* __restrict__ offs, uint64_t M,
-                                                    uint64_t total, uint32_t cutoff, uint32_t* __restrict__ out, const uint64_t* __restrict__ out_offs) {
+                                                    uint64_t total, double seqs_per_byte, uint32_t cutoff, uint32_t* __restrict__ out,
+                                                    const uint64_t* __restrict__ out_offs) {
     const IndexDev& ix = ix_;
     const uint32_t k = ix.k;
     FilterGauge fg;
@@ -419,12 +420,36 @@ __global__ void __launch_bounds__(kBlock) k_coverage(const IndexDev ix_, const u
         // (the builtin returns int: without the cast a low half with bit 31 set sign-extends over the high half, the search lands on the last
         // sequence and the positions [2^31, 2^32) mod 2^32 of a batch come back 0 — rounds 1 and 2 did that to 43 % of config 5 at full size)
         const uint64_t p0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(p_base >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)p_base);
-        uint64_t lo = 0, hi = M;                                // invariant offs[lo] <= p0 < offs[hi] (or lo == 0)
+        // the window's bytes are requested before anything is known about the sequence they belong to (a window inside the buffer can be read
+        // whether or not it lies inside ONE sequence): the loads fly while the search below waits for its offsets
+        const bool inb = p + k <= total;
+        uint64_t w0 = 0, w1 = 0, w2 = 0;
+        if (inb) { if (k == 23) load23(seqs + p, w0, w1, w2); else load13(seqs + p, w0, w1); }     // (k = 13, same box: 185 against 198 ms per 10^10 positions; k = 23 within noise)
+        // The search starts from where p0 would lie if all sequences had the mean length — exact for equal lengths, the usual batch — and
+        // gallops from there: two independent loads instead of log2(M) dependent ones per trip of every wave (20 round trips at 10^6 sequences,
+        // several times the latency of the probe itself). Any guess gives the same s.
+        uint64_t lo, hi;                                        // invariant offs[lo] <= p0 < offs[hi] (or lo == 0)
+        {
+            uint64_t g = (uint64_t)((double)p0 * seqs_per_byte);
+            if (g >= M) g = M - 1;
+            const uint64_t og = offs[g], og1 = offs[g + 1];
+            if (og <= p0) {
+                lo = g; hi = g + 1;
+                if (og1 <= p0) {
+                    uint64_t step = 1;
+                    while (hi < M && offs[hi] <= p0) { lo = hi; step <<= 1; hi = (M - lo > step) ? lo + step : M; }
+                }
+            } else {
+                hi = g; lo = g ? g - 1 : 0;
+                uint64_t step = 1;
+                while (lo > 0 && offs[lo] > p0) { hi = lo; step <<= 1; lo = lo > step ? lo - step : 0; }
+            }
+        }
         while (hi - lo > 1) {
             const uint64_t mid = (lo + hi) >> 1;
             if (offs[mid] <= p0) lo = mid; else hi = mid;
         }
-        bool active = p < total;
+        bool active = inb;
         uint64_t s = lo, begin = 0;
         if (active) {
             for (int step = 0; step < 4 && s + 1 < M && offs[s + 1] <= p; ++step) ++s;
@@ -442,12 +467,8 @@ __global__ void __launch_bounds__(kBlock) k_coverage(const IndexDev ix_, const u
         }
         uint32_t tf = 0;
         if (k == 23) {
-            uint64_t w0 = 0, w1 = 0, w2 = 0;
-            if (active) load23(seqs + p, w0, w1, w2);
             tf = query23<CANON, LPP>(ix, active, w0, w1, w2, fg).tf;
         } else if (active) {
-            uint64_t w0, w1;
-            load13(seqs + p, w0, w1);
             const Enc13 e = encode13_words(w0, w1);
             tf = e.valid ? (uint32_t)ix.tf13_code[e.code] : 0u;
         }
@@ -956,7 +977,7 @@ hipError_t launch_lookup13_ragged(const IndexDev& ix, const uint8_t* bytes, cons
 template <bool CANON, int LPP>
 static hipError_t coverage_lpp(const IndexDev& ix, const uint8_t* seqs, const uint64_t* offs, uint64_t M, uint64_t total, uint32_t cutoff, uint32_t* out,
                                const uint64_t* out_offs, hipStream_t s) {
-    AIX_LAUNCH((k_coverage<CANON, LPP>), total, s, ix, seqs, offs, M, total, cutoff, out, out_offs);
+    AIX_LAUNCH((k_coverage<CANON, LPP>), total, s, ix, seqs, offs, M, total, (double)M / (double)total, cutoff, out, out_offs);
 }
 hipError_t launch_coverage(const IndexDev& ix, const uint8_t* seqs, const uint64_t* offs, uint64_t M, uint64_t total, uint32_t cutoff, uint32_t* out,
                            const uint64_t* out_offs, hipStream_t s) {

@@ -359,6 +359,23 @@ class AindexWrapper:
         finally:
             st.lock.release()
 
+    def _tf_list_flat(self, ix: Index, flat, k: int) -> List[int]:
+        """One packed buffer of N*k query bytes -> list[int]; the answers come back into the pinned staging when it is free."""
+        from .engine import _as_u8
+        a = _as_u8(flat, k)
+        n = a.shape[0] // k
+        st, fast = self._stage, _pyfast()
+        if n >= 4096 and fast is not None and hasattr(fast, "u32_list") and st.lock.acquire(blocking=False):
+            try:
+                aout = st.view("out", 4 * n)
+                if aout is not None:
+                    out = aout[: 4 * n].view(np.uint32)
+                    ix.tf_ascii_into(a, out)
+                    return fast.u32_list(out, n, _PACK_THREADS)
+            finally:
+                st.lock.release()
+        return self._to_list(ix.tf_ascii(a))
+
     def get_tf_values_23mer(self, kmers: List[str]) -> List[int]:
         if len(kmers) == 0:
             return []
@@ -369,7 +386,7 @@ class AindexWrapper:
         if flat is None and not isinstance(kmers, (str, bytes, bytearray, memoryview, np.ndarray)):
             flat = self._join_fixed(kmers, 23)                                          # common case: a list of 23-mers
         if flat is not None:
-            return self._to_list(self._need23().tf_ascii(flat))
+            return self._tf_list_flat(self._need23(), flat, 23)
         if isinstance(kmers, (str, bytes, bytearray, memoryview)):
             kmers = [kmers]                                                             # one query of another length
         return self._to_list(self._need23().tf_ragged(kmers))                           # :1219-1228, any lengths
@@ -390,7 +407,7 @@ class AindexWrapper:
         if flat is None and not isinstance(kmers, (str, bytes, bytearray, memoryview, np.ndarray)):
             flat = self._join_fixed(kmers, 13)
         if flat is not None:
-            return self._to_list(self._ix13.tf_ascii(flat))
+            return self._tf_list_flat(self._ix13, flat, 13)
         if isinstance(kmers, (str, bytes, bytearray, memoryview)):
             kmers = [kmers]
         return self._to_list(self._ix13.tf_ragged(kmers))
