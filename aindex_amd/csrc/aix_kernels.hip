@@ -406,8 +406,10 @@ __global__ void __launch_bounds__(kBlock) k_lookup13_ragged(const IndexDev ix, c
 // ---------------------------------------------------------------------------------------------
 // coverage: one lane per byte position of the concatenated sequences (aindex.py:314-322)
 // ---------------------------------------------------------------------------------------------
+// (eight waves per SIMD: 64 VGPRs with two spilled words instead of 69 and seven waves — 268-270 against 280-282 ms per 10^10 positions on one box;
+// the same limit on k_lookup23_ascii costs 5-7 %, so it is set here only)
 template <bool CANON, int LPP>
-__global__ void __launch_bounds__(kBlock) k_coverage(const IndexDev ix_, const uint8_t* __restrict__ seqs, const uint64_t* __restrict__ offs, uint64_t M,
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) k_coverage(const IndexDev ix_, const uint8_t* __restrict__ seqs, const uint64_t* __restrict__ offs, uint64_t M,
                                                     uint64_t total, double seqs_per_byte, uint32_t cutoff, uint32_t* __restrict__ out,
                                                     const uint64_t* __restrict__ out_offs) {
     const IndexDev& ix = ix_;
