@@ -452,8 +452,12 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
             if (offs[mid] <= p0) lo = mid; else hi = mid;
         }
         bool active = inb;
-        uint64_t s = lo, begin = 0;
-        if (active) {
+        uint64_t s = lo, begin = offs[lo], obase = 0;
+        const uint64_t end0 = offs[lo + 1];
+        if (begin <= p0 && end0 > p0 + 63) {                    // all 64 positions of the wave lie in sequence lo (the usual case): nothing is looked up per lane
+            obase = out_offs[lo];
+            if (p + k > end0) active = false;
+        } else if (active) {
             for (int step = 0; step < 4 && s + 1 < M && offs[s + 1] <= p; ++step) ++s;
             if (s + 1 < M && offs[s + 1] <= p) {
                 uint64_t l2 = s + 1, h2 = M;                    // offs[l2] <= p < offs[h2]
@@ -466,6 +470,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
             begin = offs[s];
             const uint64_t end = offs[s + 1];
             if (p < begin || p + k > end) active = false;       // p < begin: gaps between sequences are allowed
+            obase = out_offs[s];
         }
         uint32_t tf = 0;
         if (k == 23) {
@@ -474,7 +479,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
             const Enc13 e = encode13_words(w0, w1);
             tf = e.valid ? (uint32_t)ix.tf13_code[e.code] : 0u;
         }
-        if (active) out[out_offs[s] + (p - begin)] = tf >= cutoff ? tf : 0u;
+        if (active) out[obase + (p - begin)] = tf >= cutoff ? tf : 0u;
     }
 }
 
