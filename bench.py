@@ -779,7 +779,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=10)          # the first ~9 launches after the index build run 4 % slower (profiles/r03/default_lookup_launches.txt)
     ap.add_argument("--workload", default="auto", choices=["auto", "lookup23", "lookup13", "count13", "count23", "gather", "coverage23", "coverage13", "positions23", "normalize", "distinct23", "e2e13", "e2e23", "selftest"],
                     help="auto: N = 1 -> lookup23 (BASELINE configs[2], the headline), N > 1 -> count23 --scaling strong (configs[3])")
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"], help="count23: strong = --total-reads split over the ranks (config 4); weak = --reads per rank")
