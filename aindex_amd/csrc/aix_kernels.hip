@@ -1061,6 +1061,12 @@ hipError_t launch_count23_fixed(const IndexDev& ix, const uint8_t* buf, uint64_t
 }
 template <int LPP>
 static hipError_t probe23_slots_lpp(const IndexDev& ix, const uint8_t* buf, uint64_t len, int canon_mode, uint32_t* slots, hipStream_t s) {
+    // AIX_PROBE_LDS_PAD=bytes (experiment): unused dynamic LDS per workgroup, to run the probe at a chosen number of waves per CU
+    static const unsigned pad = [] { const char* e = getenv("AIX_PROBE_LDS_PAD"); return e ? (unsigned)atoi(e) : 0u; }();
+    if (pad) {
+        hipLaunchKernelGGL(k_probe23_slots<LPP>, dim3(grid_for(len - 22)), dim3(kBlock), pad, s, ix, buf, len, canon_mode, slots);
+        return hipGetLastError();
+    }
     AIX_LAUNCH(k_probe23_slots<LPP>, len - 22, s, ix, buf, len, canon_mode, slots);
 }
 hipError_t launch_probe23_slots(const IndexDev& ix, const uint8_t* buf, uint64_t len, int canon_mode, uint32_t* slots, hipStream_t s) {
