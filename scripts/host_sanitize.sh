@@ -4,7 +4,7 @@
 # on the pool) — and the CPU suite run against that build. Outputs under build/ (git-ignored, not shipped to the GPU box).
 set -o pipefail
 R=$(cd "$(dirname "$0")/.." && pwd); SAN=${SAN:-address}; B=$R/build/$SAN; mkdir -p $B; cd $R/aindex_amd/csrc
-for f in aix_pool aix_reads aix_normalize aix_builder aix_api aix_kernels aix_count13 aix_positions aix_k1 aix_a2msd aix_stream23 aix_builder_gpu; do
+for f in $(ls *.hip | sed 's/\.hip$//'); do
   [ $B/$f.o -nt $f.hip ] || /opt/rocm/bin/hipcc -O1 -g -std=c++17 -fPIC --offload-arch=gfx950 -fsanitize=$SAN -fno-gpu-sanitize -fno-sanitize-recover=all -Wno-unused-result -c $f.hip -o $B/$f.o || exit 2
 done
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -fsanitize=$SAN -fno-gpu-sanitize -shared-libsan -o $B/libaindex_hip.so $B/*.o || exit 2
