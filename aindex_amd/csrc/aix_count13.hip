@@ -442,7 +442,8 @@ static hipError_t launch_split(const SRC& src, uint64_t ntiles, unsigned grid, u
                                hipStream_t s) {
     constexpr size_t lds = 4 * (3 * C13_P + C13_DUMMY + 16) + 4 * (size_t)TB * WPT;       // 155 968 B (1024 x 32) / 74 048 B (512 x 24)
     // the next tile's loads in flight during the write-out: measured SLOWER for the 13-mer source (3.45 against 3.10 ms per 10 M reads: eleven more
-    // live registers put the kernel at its 128-VGPR limit), so it is off unless asked for (A/B switch); the slot source has nothing to fetch ahead
+    // live registers put the kernel at its 128-VGPR limit), so it is off unless asked for (A/B switch); requested right after the decode instead
+    // (older than every store of the write-out): 4.27-4.42 against 4.11-4.19 ms per call, round 3. The slot source has nothing to fetch ahead
     bool prefetch = false;
     if (const char* pf = getenv("AIX_C13_PREFETCH")) prefetch = atoi(pf) != 0;
     // > 64 KiB of dynamic LDS needs the attribute; set per call (cheap, and correct for every device / thread)
