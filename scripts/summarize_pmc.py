@@ -89,7 +89,7 @@ for tag, (key, kernels) in TAGS.items():
         bj = bench_json(tag, "fetch") or {}
         cfg, roof = bj.get("config", {}), bj.get("roofline", {})
         e = {"bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr,
-             "source": f"profiles/r02/pmc_summary.txt [{tag}]: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate runs), KiB x 1024, "
+             "source": f"profiles/r03/pmc_summary.txt [{tag}]: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate runs), KiB x 1024, "
                        "FETCH_SIZE x 2 (gfx950: 128-byte requests tallied at 64 B; calibrated on k_gather). Fabric-side bytes: Infinity-Cache hits are counted."}
         for k in ("queries_per_launch", "reads_per_launch", "positions_per_launch", "windows_per_launch"):
             if k in roof:
