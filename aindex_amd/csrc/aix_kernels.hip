@@ -451,35 +451,41 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
             const uint64_t mid = (lo + hi) >> 1;
             if (offs[mid] <= p0) lo = mid; else hi = mid;
         }
-        bool active = inb;
-        uint64_t s = lo, begin = offs[lo], obase = 0;
-        const uint64_t end0 = offs[lo + 1];
-        if (begin <= p0 && end0 > p0 + 63) {                    // all 64 positions of the wave lie in sequence lo (the usual case): nothing is looked up per lane
-            obase = out_offs[lo];
-            if (p + k > end0) active = false;
-        } else if (active) {
-            for (int step = 0; step < 4 && s + 1 < M && offs[s + 1] <= p; ++step) ++s;
-            if (s + 1 < M && offs[s + 1] <= p) {
-                uint64_t l2 = s + 1, h2 = M;                    // offs[l2] <= p < offs[h2]
-                while (h2 - l2 > 1) {
-                    const uint64_t mid = (l2 + h2) >> 1;
-                    if (offs[mid] <= p) l2 = mid; else h2 = mid;
-                }
-                s = l2;
-            }
-            begin = offs[s];
-            const uint64_t end = offs[s + 1];
-            if (p < begin || p + k > end) active = false;       // p < begin: gaps between sequences are allowed
-            obase = out_offs[s];
-        }
-        uint32_t tf = 0;
-        if (k == 23) {
-            tf = query23<CANON, LPP>(ix, active, w0, w1, w2, fg).tf;
-        } else if (active) {
+        const uint64_t begin0 = offs[lo], end0 = offs[lo + 1];
+        // one probe per lane either way; the two cases are kept apart so that the usual one carries nothing per lane across the probe but the
+        // window words (its output address is a wave-uniform base plus the lane number)
+        auto answer = [&](bool active) -> uint32_t {
+            if (k == 23) return query23<CANON, LPP>(ix, active, w0, w1, w2, fg).tf;
+            if (!active) return 0u;
             const Enc13 e = encode13_words(w0, w1);
-            tf = e.valid ? (uint32_t)ix.tf13_code[e.code] : 0u;
+            return e.valid ? (uint32_t)ix.tf13_code[e.code] : 0u;
+        };
+        if (begin0 <= p0 && end0 > p0 + 63) {                   // all 64 positions of the wave lie in sequence lo (the usual case): nothing is looked up per lane
+            uint32_t* const wdst = out + (out_offs[lo] + (p0 - begin0));      // wave-uniform
+            const bool active = inb && p + k <= end0;
+            const uint32_t tf = answer(active);
+            if (active) wdst[threadIdx.x & 63u] = tf >= cutoff ? tf : 0u;
+        } else {
+            bool active = inb;
+            uint64_t s = lo;
+            uint32_t* dst = out;
+            if (active) {
+                for (int step = 0; step < 4 && s + 1 < M && offs[s + 1] <= p; ++step) ++s;
+                if (s + 1 < M && offs[s + 1] <= p) {
+                    uint64_t l2 = s + 1, h2 = M;                // offs[l2] <= p < offs[h2]
+                    while (h2 - l2 > 1) {
+                        const uint64_t mid = (l2 + h2) >> 1;
+                        if (offs[mid] <= p) l2 = mid; else h2 = mid;
+                    }
+                    s = l2;
+                }
+                const uint64_t begin = offs[s], end = offs[s + 1];
+                if (p < begin || p + k > end) active = false;   // p < begin: gaps between sequences are allowed
+                dst = out + (out_offs[s] + (p - begin));
+            }
+            const uint32_t tf = answer(active);
+            if (active) *dst = tf >= cutoff ? tf : 0u;
         }
-        if (active) out[obase + (p - begin)] = tf >= cutoff ? tf : 0u;
     }
 }
 
