@@ -128,8 +128,10 @@ struct Q23 {
     uint32_t lines;
 };
 // wave-cooperative (all lanes call it; `active` = this lane holds a query)
-template <bool CANON, int LPP>
-__device__ __forceinline__ Q23 query23(const IndexDev& ix, bool active, uint64_t w0, uint64_t w1, uint64_t w2, FilterGauge& fg) {
+// `reload(a, b, c)` fetches the query's 23 bytes again: the rare lane-by-lane path of a canonical index takes them from memory a second time instead
+// of holding the original words, their code and its reverse complement (10 VGPRs) across the wave's probe for a case that almost never comes
+template <bool CANON, int LPP, class RELOAD>
+__device__ __forceinline__ Q23 query23(const IndexDev& ix, bool active, uint64_t w0, uint64_t w1, uint64_t w2, FilterGauge& fg, RELOAD&& reload) {
     const Enc23 e = encode23_words(w0, w1, w2);
     const uint64_t r = revcomp(e.code, 23);
     Q23 out;
@@ -138,24 +140,28 @@ __device__ __forceinline__ Q23 query23(const IndexDev& ix, bool active, uint64_t
         // every stored code is canonical: only the canonical strand of a pure-ACGT query can match. ONE probe call site: with the
         // strands chosen per lane first, a wave runs Jenkins + the probe once, not once per strand with half its lanes idle
         const bool fwd = e.code <= r;
+        const bool clean = active && e.valid, other = active && !e.valid;
         uint64_t x0 = w0, x1 = w1, x2 = w2;
         if (!fwd) ascii23_of_rc(e.code, x0, x1, x2);
-        const Probe p = probe23_wave<LPP>(ix, active && e.valid, x0, x1, x2, fwd ? e.code : r, true, fg.on);
-        fg.seen(active && e.valid, p.found);
-        if (active && e.valid) {
+        const Probe p = probe23_wave<LPP>(ix, clean, x0, x1, x2, fwd ? e.code : r, true, fg.on);
+        fg.seen(clean, p.found);
+        if (clean) {
             out.lines = p.lines;
             if (p.found) { out.slot = p.slot; out.tf = p.tf; out.strand = fwd ? 1u : 2u; }
         }
-        if (active && !e.valid) {                               // other bytes: the reference's two probes, lane by lane (rare)
+        if (other) {                                            // other bytes: the reference's two probes, lane by lane (rare)
+            uint64_t v0, v1, v2;
+            reload(v0, v1, v2);
+            const Enc23 e2 = encode23_words(v0, v1, v2);
             uint64_t a, b, c;
-            jenkins23(w0, w1, w2, ix.m.seed, a, b, c);
-            const Probe f = probe23_mphf(ix, a, b, c, e.code, false);   // raw bytes hashed, sanitised code compared
+            jenkins23(v0, v1, v2, ix.m.seed, a, b, c);
+            const Probe f = probe23_mphf(ix, a, b, c, e2.code, false);   // raw bytes hashed, sanitised code compared
             out.lines = f.lines;
             if (f.found) { out.slot = f.slot; out.tf = f.tf; out.strand = 1; }
             else {
                 uint64_t r0, r1, r2;
-                ascii23_of_rc(e.code, r0, r1, r2);              // decode(reverseDNA(u)), :615-616
-                const Probe g = probe23(ix, r0, r1, r2, r);
+                ascii23_of_rc(e2.code, r0, r1, r2);             // decode(reverseDNA(u)), :615-616
+                const Probe g = probe23(ix, r0, r1, r2, revcomp(e2.code, 23));
                 out.lines += g.lines;
                 if (g.found) { out.slot = g.slot; out.tf = g.tf; out.strand = 2; }
             }
@@ -176,6 +182,10 @@ __device__ __forceinline__ Q23 query23(const IndexDev& ix, bool active, uint64_t
         }
     }
     return out;
+}
+template <bool CANON, int LPP>
+__device__ __forceinline__ Q23 query23(const IndexDev& ix, bool active, uint64_t w0, uint64_t w1, uint64_t w2, FilterGauge& fg) {
+    return query23<CANON, LPP>(ix, active, w0, w1, w2, fg, [&](uint64_t& a, uint64_t& b, uint64_t& c) { a = w0; b = w1; c = w2; });
 }
 
 // get_tf_both_directions_23mer (python_wrapper.cpp:1259-1275): Q1(q) and Q1(decode(rc(q))); wave-cooperative like query23
@@ -230,8 +240,9 @@ __global__ void __launch_bounds__(kBlock) k_lookup23_ascii(const IndexDev ix_, c
         const bool in = i < N;
         uint64_t w0 = 0, w1 = 0, w2 = 0;
         if (in) load23(q + 23 * i, w0, w1, w2);
+        auto again = [&](uint64_t& a, uint64_t& b, uint64_t& c) { load23(q + 23 * i, a, b, c); };
         if (MODE == MODE_TF) {
-            const uint32_t v = query23<CANON, LPP>(ix, in, w0, w1, w2, fg).tf;
+            const uint32_t v = query23<CANON, LPP>(ix, in, w0, w1, w2, fg, again).tf;
             if (in) out.tf[i] = v;
         } else if (MODE == MODE_LINES) {
             const uint32_t v = query23<CANON, LPP>(ix, in, w0, w1, w2, fg).lines;   // instrumentation: records read for this query
@@ -243,7 +254,7 @@ __global__ void __launch_bounds__(kBlock) k_lookup23_ascii(const IndexDev ix_, c
                 out.u64a[i] = mphf_from_hash(ix.m, a, b, c);
             }
         } else if (MODE == MODE_KIDSTRAND) {
-            const Q23 r = query23<CANON, LPP>(ix, in, w0, w1, w2, fg);
+            const Q23 r = query23<CANON, LPP>(ix, in, w0, w1, w2, fg, again);
             if (in) {
                 if (out.u64a) out.u64a[i] = r.slot;             // get_kid_by_kmer: 0 when absent (:700-716)
                 if (out.strand) out.strand[i] = (uint8_t)r.strand;
@@ -455,7 +466,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 
         // one probe per lane either way; the two cases are kept apart so that the usual one carries nothing per lane across the probe but the
         // window words (its output address is a wave-uniform base plus the lane number)
         auto answer = [&](bool active) -> uint32_t {
-            if (k == 23) return query23<CANON, LPP>(ix, active, w0, w1, w2, fg).tf;
+            if (k == 23) return query23<CANON, LPP>(ix, active, w0, w1, w2, fg, [&](uint64_t& a, uint64_t& b, uint64_t& c) { load23(seqs + p, a, b, c); }).tf;
             if (!active) return 0u;
             const Enc13 e = encode13_words(w0, w1);
             return e.valid ? (uint32_t)ix.tf13_code[e.code] : 0u;
