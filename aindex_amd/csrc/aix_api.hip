@@ -634,6 +634,38 @@ extern "C" int aix_debug_relocate_bloom(aix_index_t* h, uint64_t pad_bytes) {
     return AIX_OK;
 }
 
+// Move any subset of a 23-mer handle's device arrays into freshly allocated blocks (mask: 1 MPHF records, 2 side index, 4 unfiled keys, 8 verification
+// table, 16 absence filter); the old blocks are NOT freed, so that the new ones come from other memory. Placement experiments only
+// (scripts/experiments/r3/rehome.py).
+extern "C" int aix_debug_rehome(aix_index_t* h, uint32_t mask) {
+    if (!h || h->k != 23) return AIX_ERR_ARG;
+    DevGuard g(h->device);
+    auto move = [&](void** field, uint64_t bytes) -> int {
+        if (!*field || !bytes) return AIX_OK;
+        void* nb_ = nullptr;
+        HIPCHK(hipMalloc(&nb_, bytes));
+        HIPCHK(hipMemcpy(nb_, *field, bytes, hipMemcpyDeviceToDevice));
+        *field = nb_;
+        return AIX_OK;
+    };
+    int st = AIX_OK;
+    if (!st && (mask & 1)) st = move((void**)&h->recs, (uint64_t)((h->B + 15) / 16) * sizeof(BvRec));
+    if (!st && (mask & 2)) st = move((void**)&h->side, 4ull * h->n);
+    if (!st && (mask & 4)) st = move((void**)&h->unfiled, (uint64_t)h->n_unfiled * sizeof(KeyRec));
+    if (!st && (mask & 8) && !h->bk_borrowed) st = move((void**)&h->bk, (uint64_t)h->nb * 8 * sizeof(BkEntry));
+    if (!st && (mask & 16)) st = move((void**)&h->bloom, 8ull * h->nbloom);
+    HIPCHK(hipDeviceSynchronize());
+    return st;
+}
+
+// device addresses of a handle's arrays (same order as the mask bits of aix_debug_rehome): experiments only
+extern "C" int aix_debug_pointers(const aix_index_t* h, uint64_t out[5]) {
+    if (!h || !out) return AIX_ERR_ARG;
+    out[0] = (uint64_t)(uintptr_t)h->recs; out[1] = (uint64_t)(uintptr_t)h->side; out[2] = (uint64_t)(uintptr_t)h->unfiled;
+    out[3] = (uint64_t)(uintptr_t)h->bk; out[4] = (uint64_t)(uintptr_t)h->bloom;
+    return AIX_OK;
+}
+
 extern "C" int aix_index_set_tf_13(aix_index_t* h, const uint64_t* tf) {
     if (!h || !tf) return AIX_ERR_ARG;
     if (h->k != 13) return AIX_ERR_MODE;

@@ -418,6 +418,8 @@ int aix_bench_gather_dev(const void* d_table, uint64_t n_elems, int elem_bytes, 
  * that successive moves land on different pages). Answers are unchanged. Not for production use. */
 int aix_debug_relocate_table(aix_index_t* h, void* d_dst);
 int aix_debug_relocate_bloom(aix_index_t* h, uint64_t pad_bytes);
+int aix_debug_pointers(const aix_index_t* h, uint64_t out[5]);   /* device addresses: MPHF records, side index, unfiled keys, table, absence filter */
+int aix_debug_rehome(aix_index_t* h, uint32_t mask);   /* 1 MPHF records, 2 side index, 4 unfiled keys, 8 table, 16 absence filter -> fresh blocks */
 
 /* self-test hook for the CPU test-suite: the exact-modulo used by the kernels, run on the host */
 uint64_t aix_selftest_mod(uint64_t h, uint64_t d);
