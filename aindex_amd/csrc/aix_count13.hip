@@ -336,23 +336,9 @@ __global__ void __launch_bounds__(C13_TB) k_c13_hist_chunked(const uint16_t* __r
     uint32_t* h = (uint32_t*)smem;                              // [BINS]
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t p = blockIdx.x; p < (uint32_t)C13_P; p += gridDim.x) {
-        if (wave == 0) {
-            // lower_bound of p (lanes 0-31) and of p + 1 (lanes 32-63) in the sorted partition ids, 32 probes per round: five rounds of independent
-            // loads instead of 22 dependent ones — every other wave of the workgroup waits for this at the barrier below
-            const uint32_t key = p + (lane >> 5), l5 = lane & 31u;
-            uint32_t lo = 0, hi = cap;                           // answer in [lo, hi]; spart[i] < key for i < lo, spart[i] >= key for i >= hi
-            while (hi - lo > 0) {
-                const uint32_t span = hi - lo, step = (span + 32) / 33;         // probes at lo + step - 1, lo + 2 step - 1, ...: the last one inside [lo, hi)
-                const uint32_t at = lo + (l5 + 1) * step - 1;
-                const bool less = at < hi && spart[at] < key;
-                const uint64_t b = __ballot(less);
-                const uint32_t nless = (uint32_t)__popc((uint32_t)(lane >> 5 ? b >> 32 : b));   // probes are ordered: the first nless say "less"
-                const uint32_t nlo = lo + nless * step;          // everything up to the last "less" probe is < key
-                const uint32_t nhi = min(hi, lo + (nless + 1) * step - 1);      // the first "not less" probe (or hi) bounds the answer
-                lo = min(nlo, hi);
-                hi = max(nhi, lo);
-            }
-            if (l5 == 0) range[lane >> 5] = lo;
+        if (wave == 0) {                                        // every other wave of the workgroup waits for this at the barrier below
+            const uint32_t r = wave_lower_bound_pair(spart, cap, p);
+            if ((lane & 31u) == 0) range[lane >> 5] = r;
         }
         for (int i = threadIdx.x; i < C13_BINS; i += C13_TB) h[i] = 0;
         __syncthreads();

@@ -158,11 +158,9 @@ __global__ void __launch_bounds__(K1_TB) k_k1_split(const SRC src, uint32_t s1, 
 
 // chunk range [lo, hi) of partition p in the directory sorted by partition
 __device__ __forceinline__ void partition_range(const uint16_t* __restrict__ spart, uint32_t cap, uint32_t p, uint32_t* range /* LDS[2] */) {
-    if (threadIdx.x < 2) {
-        const uint32_t key = p + threadIdx.x;
-        uint32_t lo = 0, hi = cap;
-        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (spart[mid] < key) lo = mid + 1; else hi = mid; }
-        range[threadIdx.x] = lo;
+    if (threadIdx.x < 64) {                                      // wave 0; the others wait at the barrier
+        const uint32_t r = wave_lower_bound_pair(spart, cap, p);
+        if ((threadIdx.x & 31u) == 0) range[threadIdx.x >> 5] = r;
     }
     __syncthreads();
 }
