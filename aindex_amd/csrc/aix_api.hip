@@ -671,6 +671,7 @@ extern "C" int aix_index_set_tf_13(aix_index_t* h, const uint64_t* tf) {
     if (h->k != 13) return AIX_ERR_MODE;
     DevGuard g(h->device);
     HIPCHK(hipMemcpy(h->tf13_mphf, tf, 8 * AIX_TOTAL_13MERS, hipMemcpyHostToDevice));
+    h->pos_total_known = false;
     HIPCHK(launch_tf13_to_code_order(h->perm13, h->tf13_mphf, h->tf13_code, 0));
     HIPCHK(hipStreamSynchronize(0));
     return AIX_OK;
@@ -1584,10 +1585,13 @@ extern "C" int aix_positions_total(aix_index_t* h, uint64_t* total_out) {
     DevGuard g(h->device);
     *total_out = 0;
     if (h->n == 0) return AIX_OK;
+    if (h->pos_total_known) { *total_out = h->pos_total; return AIX_OK; }       // sum of tf[]: fixed for the life of a 23-mer handle, reset by aix_index_set_tf_13
     DevBuf dind;
     HIPCHK(dind.alloc(8 * (h->n + 1)));
     HIPCHK(positions_indices(h->dev(), (uint64_t*)dind.p, 0));
     HIPCHK(hipMemcpy(total_out, (const uint64_t*)dind.p + h->n, 8, hipMemcpyDeviceToHost));
+    h->pos_total = *total_out;
+    h->pos_total_known = true;
     return AIX_OK;
 }
 

@@ -105,6 +105,8 @@ struct aix_index {
     bool fp_filter = true;
     bool early_exit = true;                    // (used when the early-exit table exists: built at open only without a verification table, else on request)
     std::mutex count_mutex;
+    uint64_t pos_total = 0;                        // aix_positions_total, once computed (sum of tf[])
+    bool pos_total_known = false;
     uint32_t a2_backend = 0;                       // the last positions fill: bit 0 = stable radix sort, bit 1 = MSD partition (per piece)
     uint32_t c23_backend = 0, c23_passes = 0;     // the last aix_count23_fixed*: 1 = memory-side atomics, 2 = slot stream + LDS histogram; passes over the slot stream
     bool c13_atomics = false, c13_added = false;   // state of a 13-mer count in progress (between count13_begin_locked and count13_end_locked)
