@@ -146,6 +146,7 @@ SIGNATURES = {
     "aix_host_free": (i32, [vp]),
     "aix_debug_relocate_table": (i32, [vp, vp]),
     "aix_debug_relocate_bloom": (i32, [vp, u64]),
+    "aix_selftest_lower_bound_dev": (i32, [vp, C.c_uint32, vp, C.c_uint32, vp, vp]),
     "aix_debug_rehome": (i32, [vp, C.c_uint32]),
     "aix_debug_pointers": (i32, [vp, C.POINTER(u64)]),
     "aix_selftest_mod": (u64, [u64, u64]),

@@ -658,6 +658,14 @@ extern "C" int aix_debug_rehome(aix_index_t* h, uint32_t mask) {
     return st;
 }
 
+// GPU self-test hook of the suite: lower bounds of keys[i] and keys[i] + 1 in a sorted u16 array, by the wave-wide search the partition kernels
+// use to find a partition's chunks (out[2 i], out[2 i + 1]); all pointers are device pointers
+extern "C" int aix_selftest_lower_bound_dev(const uint16_t* d_sorted, uint32_t n, const uint32_t* d_keys, uint32_t nkeys, uint32_t* d_out, void* stream) {
+    if ((n && !d_sorted) || (nkeys && (!d_keys || !d_out))) return AIX_ERR_ARG;
+    HIPCHK(launch_selftest_lower_bound(d_sorted, n, d_keys, nkeys, d_out, (hipStream_t)stream));
+    return AIX_OK;
+}
+
 // device addresses of a handle's arrays (same order as the mask bits of aix_debug_rehome): experiments only
 extern "C" int aix_debug_pointers(const aix_index_t* h, uint64_t out[5]) {
     if (!h || !out) return AIX_ERR_ARG;

@@ -429,7 +429,7 @@ __device__ __forceinline__ uint32_t wave_lower_bound_pair(const uint16_t* __rest
         const uint64_t b = __ballot(less);
         const uint32_t nless = (uint32_t)__popc((uint32_t)(half ? b >> 32 : b));   // sorted input: the first nless probes say "less"
         const uint32_t nlo = min(lo + nless * step, hi);     // everything up to the last "less" probe is < key
-        const uint32_t nhi = min(hi, lo + (nless + 1) * step - 1);      // the first "not less" probe bounds the answer
+        const uint32_t nhi = nless == 32u ? hi : min(hi, lo + (nless + 1) * step - 1);      // the first "not less" probe bounds the answer (there is none when all 32 said "less")
         lo = nlo;
         hi = max(nhi, lo);
     }

@@ -67,6 +67,7 @@ void pool_trim();
 // launchers (aix_kernels.hip). All asynchronous on `stream`; return hipGetLastError().
 hipError_t launch_lookup23_ascii(const IndexDev& ix, const uint8_t* q, uint64_t N, int mode, LookupOut out, hipStream_t s);
 hipError_t launch_lookup23_codes(const IndexDev& ix, const uint64_t* codes, uint64_t N, uint32_t* out, hipStream_t s);
+hipError_t launch_selftest_lower_bound(const uint16_t* a, uint32_t n, const uint32_t* keys, uint32_t nkeys, uint32_t* out, hipStream_t s);
 hipError_t launch_lookup23_ragged(const IndexDev& ix, const uint8_t* bytes, const uint64_t* offs, uint64_t N, uint32_t* out, hipStream_t s);
 hipError_t launch_lookup13_ascii(const IndexDev& ix, const uint8_t* q, uint64_t N, int mode, LookupOut out, hipStream_t s);
 hipError_t launch_lookup13_ragged(const IndexDev& ix, const uint8_t* bytes, const uint64_t* offs, uint64_t N, uint32_t* out, hipStream_t s);

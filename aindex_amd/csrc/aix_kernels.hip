@@ -975,6 +975,16 @@ hipError_t launch_lookup23_ascii(const IndexDev& ix, const uint8_t* q, uint64_t 
     if (N == 0) return hipSuccess;
     return ix.canonical_only ? lookup23_ascii_mode<true>(ix, q, N, mode, out, s) : lookup23_ascii_mode<false>(ix, q, N, mode, out, s);
 }
+// self-test of wave_lower_bound_pair (aix_device.hpp): wave w of the grid looks up keys[w] and keys[w] + 1 in the sorted array
+__global__ void __launch_bounds__(64) k_selftest_lower_bound(const uint16_t* __restrict__ a, uint32_t n, const uint32_t* __restrict__ keys, uint32_t* __restrict__ out) {
+    const uint32_t r = wave_lower_bound_pair(a, n, keys[blockIdx.x]);
+    if ((threadIdx.x & 31u) == 0) out[2 * blockIdx.x + (threadIdx.x >> 5)] = r;
+}
+hipError_t launch_selftest_lower_bound(const uint16_t* a, uint32_t n, const uint32_t* keys, uint32_t nkeys, uint32_t* out, hipStream_t s) {
+    if (nkeys == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_selftest_lower_bound, dim3(nkeys), dim3(64), 0, s, a, n, keys, out);
+    return hipGetLastError();
+}
 hipError_t launch_lookup23_codes(const IndexDev& ix, const uint64_t* codes, uint64_t N, uint32_t* out, hipStream_t s) {
     if (N == 0) return hipSuccess;
     if (ix.canonical_only) AIX_LAUNCH((k_lookup23_codes<true, 8>), N, s, ix, codes, N, out);

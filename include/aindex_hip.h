@@ -421,6 +421,10 @@ int aix_debug_relocate_bloom(aix_index_t* h, uint64_t pad_bytes);
 int aix_debug_pointers(const aix_index_t* h, uint64_t out[5]);   /* device addresses: MPHF records, side index, unfiled keys, table, absence filter */
 int aix_debug_rehome(aix_index_t* h, uint32_t mask);   /* 1 MPHF records, 2 side index, 4 unfiled keys, 8 table, 16 absence filter -> fresh blocks */
 
+/* self-test hook of the GPU suite: lower bounds of keys[i] and keys[i] + 1 in a sorted u16 array of n entries, computed by the wave-wide search with
+ * which the partition kernels find a partition's chunks; out[2 i], out[2 i + 1]. Device pointers. */
+int aix_selftest_lower_bound_dev(const uint16_t* d_sorted, uint32_t n, const uint32_t* d_keys, uint32_t nkeys, uint32_t* d_out, void* stream);
+
 /* self-test hook for the CPU test-suite: the exact-modulo used by the kernels, run on the host */
 uint64_t aix_selftest_mod(uint64_t h, uint64_t d);
 uint64_t aix_selftest_revcomp(uint64_t code, int k);

@@ -1126,6 +1126,29 @@ def test_config3_full_size_index_against_the_oracle(config3_index, tmp_path):
     assert np.array_equal(ix.tf_ascii(sub), want[::40])
 
 
+def test_wave_lower_bound_of_the_partition_kernels():
+    """The wave-wide search with which the histogram / MSD kernels find a partition's chunks in the sorted directory (32 probes per round), against
+    numpy.searchsorted: every key of directories whose sizes make a round's span a multiple of 33 (where the first version, for which every probe of
+    a round said "less", cut the upper bound by one and handed a chunk to the next partition: 371 of 2.5e10 windows at config-4 size), sizes 0 and 1,
+    few and many distinct values."""
+    import torch
+    from aindex_amd._lib import lib, check, vp
+    rng = np.random.default_rng(33)
+    sizes = [0, 1, 2, 31, 32, 33, 34, 65, 66, 33 * 33, 33 * 33 + 1, 33 * 34, 33 ** 3, 33 ** 3 - 1, 2 * 33 ** 3, 3042, 2202, 1_000_003, 4_000_000] + [int(x) for x in rng.integers(2, 300_000, size=25)]
+    for n in sizes:
+        for nv in (1, 3, 2049):
+            a = np.sort(rng.integers(0, nv, size=n)).astype(np.uint16)
+            keys = np.arange(0, min(nv, 2049) + 2, dtype=np.uint32) if nv < 100 else np.concatenate([rng.integers(0, 2050, size=200), [0, 2047, 2048, 2049]]).astype(np.uint32)
+            da = torch.from_numpy(a.view(np.int16)).cuda() if n else torch.zeros(1, dtype=torch.int16, device="cuda")
+            dk = torch.from_numpy(keys.view(np.int32)).cuda()
+            out = torch.empty(2 * keys.shape[0], dtype=torch.int32, device="cuda")
+            check(lib().aix_selftest_lower_bound_dev(vp(da.data_ptr()), n, vp(dk.data_ptr()), keys.shape[0], vp(out.data_ptr()), None), "selftest_lower_bound")
+            torch.cuda.synchronize()
+            got = out.cpu().numpy().view(np.uint32).reshape(-1, 2)
+            want = np.stack([np.searchsorted(a, keys, side="left"), np.searchsorted(a, keys + 1, side="left")], axis=1).astype(np.uint32)
+            assert np.array_equal(got, want), (n, nv, keys[np.nonzero((got != want).any(axis=1))[0][:4]])
+
+
 def test_config5_coverage_full_size_properties(config3_index, ix13):
     """Config 5 at its FULL size (1 M sequences x 10 kbp, as the bench runs it; round 2 tested a tenth): the per-position profile equals
     the batch lookup of every window, checked on sampled sequences, for k = 23 (index of config 3) and k = 13. 10 GB of sequences and a
