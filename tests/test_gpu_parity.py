@@ -1044,6 +1044,13 @@ def test_config4_share_of_25M_reads_properties(config3_index):
     valid = int((inside == 0).sum().item())
     del is_n, c, inside
     assert int(tf.to(torch.int64).sum().item()) == valid and valid > n_reads * 100
+    # K1 on ALL the reads (three pieces merged): every distinct k-mer it reports is a key of the index, and its counts are the histogram's
+    # (a chunk handed to the neighbouring partition shows up as keys the index does not hold: the round-3 search bug, found at 200 M reads)
+    k_all, c_all = counting.count_distinct_t(reads, 23, _lib.CANON_TRUE_RC)
+    assert bool((ix.tf_codes_t(k_all) != 0).all()) and bool((k_all[1:] > k_all[:-1]).all())
+    tfl = tf.to(torch.int64)
+    assert torch.equal(torch.sort(tfl[tfl > 0]).values, torch.sort(c_all.to(torch.int64)).values)
+    del k_all, c_all, tfl
     keys, counts = counting.count_distinct_t(reads[: 5_000_000 * 151], 23, _lib.CANON_TRUE_RC)       # sort / run-length of the first 5 M reads
     tf5 = ix.count23_fixed_t(reads[: 5_000_000 * 151], _lib.CANON_TRUE_RC).to(torch.int64)
     assert torch.equal(torch.sort(tf5[tf5 > 0]).values, torch.sort(counts).values)
