@@ -932,6 +932,31 @@ extern "C" int aix_count23_fixed_dev(aix_index_t* h, const char* d_plain, uint64
         h->c23_backend = 1; h->c23_passes = 0;
         return AIX_OK;
     }
+    // (c) counting the distinct k-mers of the reads first (K1: MSD partition + per-bucket LDS hash, pieces merged) and probing each of them ONCE:
+    // when the reads hold every key many times over, K1's LDS-bound 21 ps per window beat a 128-byte line per window (config 4: 200 M reads against
+    // 5e7 keys = 512 windows per key, 531 against 617 - 679 ms). Taken from 64 windows per key and 2^31 windows up (AIX_COUNT23_VIA_K1=0 / 1 forces);
+    // if K1's scratch does not fit the call goes on with (b). Same histogram: every window is counted under the same canonical form, skipped for the
+    // same bytes, and two distinct k-mers never share a slot.
+    bool via_k1 = nwin >= (1ull << 31) && nwin / 64 >= h->n;
+    if (const char* e = getenv("AIX_COUNT23_VIA_K1")) via_k1 = atoi(e) != 0;
+    if (via_k1) {
+        uint64_t *dk = nullptr, *dc = nullptr, dn = 0;
+        uint64_t piece = 0;
+        if (const char* e = getenv("AIX_DISTINCT_PIECE")) piece = strtoull(e, nullptr, 10);
+        const hipError_t e = distinct_from_plain((const uint8_t*)d_plain, len, 23, canon_mode, 1, piece, &dk, &dc, &dn, s);
+        if (e == hipSuccess) {
+            const hipError_t e2 = launch_add_counts23(h->dev_slots(), dk, dc, dn, d_tf_out, s);
+            const hipError_t e3 = hipStreamSynchronize(s);                     // the K1 result goes back to the block cache idle
+            if (dk) pool_free(dk);
+            if (dc) pool_free(dc);
+            HIPCHK(e2);
+            HIPCHK(e3);
+            h->c23_backend = 3; h->c23_passes = 0;
+            return AIX_OK;
+        }
+        (void)hipGetLastError();
+        if (e != hipErrorOutOfMemory) { set_last_error(std::string("count23 through K1: ") + hipGetErrorString(e)); return AIX_ERR_HIP; }
+    }
     uint32_t range_bits = 26;                                                  // AIX_COUNT23_TEST_RANGE_BITS: test hook, several slot ranges on a small key set
     if (const char* e = getenv("AIX_COUNT23_TEST_RANGE_BITS")) { const int v = atoi(e); if (v >= 4 && v <= 26) range_bits = (uint32_t)v; }
     std::lock_guard<std::mutex> lk(h->count_mutex);

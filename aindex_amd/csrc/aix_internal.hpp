@@ -112,6 +112,8 @@ hipError_t launch_run23_slots(const IndexDev& ix, const uint8_t* buf, uint64_t l
 hipError_t launch_scatter13_to_mphf(const uint32_t* perm, const unsigned long long* table_code, uint64_t* out_mphf, int add, hipStream_t s);
 hipError_t launch_perm13_check(const uint32_t* perm, uint32_t* bits /* 4^13 / 32 zeroed words */, uint32_t* bad /* zeroed */, hipStream_t s);
 hipError_t launch_count23_fixed(const IndexDev& ix, const uint8_t* buf, uint64_t len, int canon_mode, uint32_t* tf_out, hipStream_t s);
+hipError_t launch_add_counts23(const IndexDev& ix, const uint64_t* keys /* distinct, in the call's canonical form */, const uint64_t* counts, uint64_t n, uint32_t* tf_out,
+                               hipStream_t s);
 
 hipError_t launch_window_codes(const uint8_t* buf, uint64_t len, int k, int canon_mode, uint64_t* out /* [len-k+1] */, hipStream_t s);
 

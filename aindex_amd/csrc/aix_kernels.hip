@@ -786,6 +786,24 @@ __global__ void __launch_bounds__(kBlock) k_probe23_slots(const IndexDev ix, con
     }
 }
 
+// count23 through K1: the distinct k-mers of the reads (already in the call's canonical form) with their counts; one probe per DISTINCT k-mer, and a plain
+// read-modify-write of its slot — two distinct k-mers never share a slot
+template <int LPP>
+__global__ void __launch_bounds__(kBlock) k_add_counts23(const IndexDev ix, const uint64_t* __restrict__ keys, const uint64_t* __restrict__ counts, uint64_t n,
+                                                        uint32_t* __restrict__ tf_out) {
+    IndexDev ixn = ix;
+    ixn.bloom = nullptr;
+    ixn.early_exit = 0;
+    AIX_WAVE_LOOP(i, n) {
+        const bool in = i < n;
+        const uint64_t key = in ? keys[i] : 0ull;
+        uint64_t s0, s1, s2;
+        ascii23_of_rc(revcomp(key, 23), s0, s1, s2);
+        const Probe pr = probe23_wave<LPP>(ixn, in, s0, s1, s2, key);
+        if (in && pr.found) tf_out[pr.slot] += (uint32_t)counts[i];          // u32 histogram: wraps like the per-window adds of the other back ends
+    }
+}
+
 // K1 front end (count_kmers.cpp:93-136,297-308): the canonical 2-bit code of every window of a PLAIN
 // buffer, ~0 where the window holds a non-base byte. Distinct counting = sort + run-length of this.
 template <int K>
@@ -1101,6 +1119,10 @@ hipError_t launch_probe23_slots(const IndexDev& ix, const uint8_t* buf, uint64_t
 #define AIX_CALL(L) probe23_slots_lpp<L>(ix, buf, len, canon_mode, slots, s)
     AIX_LPP_SWITCH(ix.bk_lpp, AIX_CALL)
 #undef AIX_CALL
+}
+hipError_t launch_add_counts23(const IndexDev& ix, const uint64_t* keys, const uint64_t* counts, uint64_t n, uint32_t* tf_out, hipStream_t s) {
+    if (n == 0 || ix.n == 0) return hipSuccess;
+    AIX_LAUNCH(k_add_counts23<2>, n, s, ix, keys, counts, n, tf_out);
 }
 hipError_t launch_window_codes(const uint8_t* buf, uint64_t len, int k, int canon_mode, uint64_t* out, hipStream_t s) {
     if (len < (uint64_t)k) return hipSuccess;

@@ -653,6 +653,21 @@ def count23_roofline(ix, windows, reads, kern_ms):
     hit L1), one probe of the verification table per valid window, one 4-byte counter RMW (4 read + 4 written, memory side).
     The reference algorithm's figure for the same windows (1.17 + 154 + 8 B) is kept beside it for orientation."""
     p = ix.probe_profile()
+    if ix.info["count23_backend"] == 3:
+        # the call counted the distinct k-mers of the reads first (K1) and probed each of them once: what moves per window is K1's traffic (the MSD
+        # path: 1.18 B of reads in, 8 B codes written once, read and written at level 1, read twice + 4 B remainders at level 2, read again), plus
+        # one probe and 24 B per DISTINCT k-mer — not a table line per window. The pipeline is bound by LDS atomics, not by HBM (DESIGN.md 4).
+        per_window = 151.0 / 128.0 + 8.0 + 16.0 + 20.0 + 4.0
+        per_key = 24.0 + p["bytes_per_hit_probe"] + 8.0
+        achieved = (windows * per_window + ix.n * per_key) / (kern_ms * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "k_k1_split / k_k1_count / k_k1_scatter / k_k1_final / k_k1_gather per piece + k_merge_tile + k_add_counts23 (aix_count23_fixed_dev, back end 3)",
+                "kernel_ms": kern_ms, "requested_bytes_per_window": per_window, "requested_bytes_per_distinct_kmer": per_key, "windows_per_launch": windows,
+                "reads_per_launch": reads, "windows_per_key": windows / max(1, ix.n),
+                "note": "not HBM-bound: one returning LDS atomic per window and partition level; the probe path (back end 2, AIX_COUNT23_VIA_K1=0) requests "
+                        f"{151.0 / 128.0 + p['bytes_per_hit_probe'] + 8.0:.1f} B per window and ran at 617 - 679 ms on this workload (DESIGN.md 5)",
+                "reference_algorithm": {"bytes_per_window": 1.17 + 154.0 + 8.0, "GBps": windows * (1.17 + 154.0 + 8.0) / (kern_ms * 1e-3) / 1e9,
+                                        "note": "SURVEY 8(d): what mphf::lookup + checker + tf would move per window; not what this path moves"}}
     per_window = 151.0 / 128.0 + p["bytes_per_hit_probe"] + 8.0
     achieved = windows * per_window / (kern_ms * 1e-3) / 1e9
     lines = p["lines_per_hit_probe"]
@@ -751,8 +766,8 @@ def measure_count23_strong(ix, g, rank, world, dev, total_reads, steps, warmup):
             "scaling": "strong", "total_reads": total_reads, "reads_this_rank": hi - lo, "ms_per_step": wall / steps * 1e3,
             "allreduce_ms": ar_ms, "allreduce_bytes": 4 * ix.n, "collective": f"all_reduce(sum) of int32 tf[{ix.n}]" if backend != "none" else "none (1 rank)",
             "backend": backend, "collective_ranks": world if backend != "none" else 1,
-            "kernel": "k_count23_fixed", "kernel_ms_this_rank": k_ms, "windows_this_rank": windows_rank,
-            "counting_backend": {1: "memory-side atomics", 2: "slot stream + LDS histogram"}.get(ix.info["count23_backend"], "none"),
+            "kernel": "aix_count23_fixed_dev", "kernel_ms_this_rank": k_ms, "windows_this_rank": windows_rank,
+            "counting_backend": {1: "memory-side atomics", 2: "slot stream + LDS histogram", 3: "distinct k-mers first (K1), one probe per distinct k-mer"}.get(ix.info["count23_backend"], "none"),
             "histogram_passes": ix.info["count23_passes"],
             "windows_counted_all_ranks": digest["sum"], "windows_without_N_all_ranks": int(clean.item()), "tf_digest": digest,
             "one_device_rehearsal": bool(os.environ.get("AIX_BENCH_ONE_DEVICE"))}

@@ -1058,6 +1058,17 @@ def test_config4_share_of_25M_reads_properties(config3_index):
     kid, strand = ix.kid_strand_ascii(synth.decode_kmers(keys[pick].cpu().numpy().view(np.uint64), 23))
     assert (strand == 1).all()
     assert np.array_equal(tf5.cpu().numpy()[kid.astype(np.int64)], counts[pick].cpu().numpy())
+    # the three back ends give one histogram: the probe + LDS-histogram path and the "distinct k-mers first" path forced in turn (25 M reads against
+    # 5e7 keys sit right at the 64-windows-per-key threshold of the automatic choice), the atomics path below
+    for force, backend in (("1", 3), ("0", 2)):
+        os.environ["AIX_COUNT23_VIA_K1"] = force
+        try:
+            tf_k = ix.count23_fixed_t(reads, _lib.CANON_TRUE_RC)
+            assert ix.info["count23_backend"] == backend
+        finally:
+            del os.environ["AIX_COUNT23_VIA_K1"]
+        assert torch.equal(tf_k, tf)
+        del tf_k
     os.environ["AIX_COUNT23_ATOMICS"] = "1"
     try:
         tf_a = ix.count23_fixed_t(reads, _lib.CANON_TRUE_RC)
@@ -1686,6 +1697,20 @@ def test_count23_histogram_backend_equals_atomics_and_oracle(canon_case, small23
                     monkeypatch.delenv("AIX_COUNT23_RUN")
                     ix.set_bucket_table(True, 2)
                 ix.set_bucket_table(True)
+                # back end 3: the distinct k-mers of the buffer first (K1, in one piece and in pieces merged), one probe per distinct k-mer
+                monkeypatch.setenv("AIX_COUNT23_VIA_K1", "1")
+                for dpiece in (None, "5000", "33333"):
+                    if dpiece is None:
+                        monkeypatch.delenv("AIX_DISTINCT_PIECE", raising=False)
+                    else:
+                        monkeypatch.setenv("AIX_DISTINCT_PIECE", dpiece)
+                    for bk in (True, False):
+                        ix.set_bucket_table(bk)
+                        assert np.array_equal(ix.count23_fixed(buf, _lib.FMT_PLAIN, mode), want), (mode, "via K1", dpiece, bk)
+                        assert ix.info["count23_backend"] == 3
+                ix.set_bucket_table(True)
+                monkeypatch.delenv("AIX_DISTINCT_PIECE", raising=False)
+                monkeypatch.delenv("AIX_COUNT23_VIA_K1")
                 ix.set_minimizer_table(True)
                 monkeypatch.delenv("AIX_COUNT23_PIECE", raising=False)
                 t = torch.frombuffer(bytearray(buf), dtype=torch.uint8).cuda()
