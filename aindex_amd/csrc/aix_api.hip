@@ -933,11 +933,12 @@ extern "C" int aix_count23_fixed_dev(aix_index_t* h, const char* d_plain, uint64
         return AIX_OK;
     }
     // (c) counting the distinct k-mers of the reads first (K1: MSD partition + per-bucket LDS hash, pieces merged) and probing each of them ONCE:
-    // when the reads hold every key many times over, K1's LDS-bound 21 ps per window beat a 128-byte line per window (config 4: 200 M reads against
-    // 5e7 keys = 512 windows per key, 531 against 617 - 679 ms). Taken from 64 windows per key and 2^31 windows up (AIX_COUNT23_VIA_K1=0 / 1 forces);
-    // if K1's scratch does not fit the call goes on with (b). Same histogram: every window is counted under the same canonical form, skipped for the
-    // same bytes, and two distinct k-mers never share a slot.
-    bool via_k1 = nwin >= (1ull << 31) && nwin / 64 >= h->n;
+    // K1's LDS-bound 21 ps per window beat a 128-byte line per window (24 - 27 ps) as soon as the distinct k-mers — at most n — are few against the
+    // windows: 34.7 / 69.8 / 138 / 272 ms against 43.0 / 85.7 / 171 / 341 ms at 32 / 64 / 128 / 256 windows per key (5e7 keys, one handle), config 4
+    // 531 against 617 - 679 ms; the extra probe per distinct k-mer (28 ps) is paid back from ~6 windows per key. Taken from 8 windows per key and
+    // 2^29 windows up (AIX_COUNT23_VIA_K1=0 / 1 forces); if K1's scratch does not fit the call goes on with (b). Same histogram: every window is
+    // counted under the same canonical form, skipped for the same bytes, and two distinct k-mers never share a slot.
+    bool via_k1 = nwin >= (1ull << 29) && nwin / 8 >= h->n;
     if (const char* e = getenv("AIX_COUNT23_VIA_K1")) via_k1 = atoi(e) != 0;
     if (via_k1) {
         uint64_t *dk = nullptr, *dc = nullptr, dn = 0;

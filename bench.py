@@ -824,12 +824,15 @@ def main():
     ap.add_argument("--no-fingerprint", action="store_true", help="disable the 4-bit fingerprint filter")
     ap.add_argument("--no-early-exit", action="store_true", help="disable the early-exit MPHF walk (presence masks)")
     ap.add_argument("--no-bucket-table", action="store_true", help="switch the verification table off (every probe through the MPHF records + key records)")
+    ap.add_argument("--probe-path", action="store_true", help="count23: keep the per-window probe + LDS-histogram back end (AIX_COUNT23_VIA_K1=0) where the call would count distinct k-mers first")
     ap.add_argument("--no-minimizer-table", action="store_true", help="streaming consumers (count23, coverage, positions) probe the hash-keyed table: one HBM line per window")
     ap.add_argument("--no-absence-filter", action="store_true", help="switch the Bloom filter in front of the verification table off")
     ap.add_argument("--bucket-lanes", type=int, default=0, choices=[0, 1, 2, 4, 8], help="lanes that share one bucket read (0: the library's default)")
     ap.add_argument("--gpu-builder", action="store_true", help="build the MPHF on the GPU (parallel peeling) instead of the host")
     ap.add_argument("--query-mix", action="store_true", help="Q_mix: 50 %% genome windows on a random strand + 50 %% random (seed 8)")
     a = ap.parse_args()
+    if a.probe_path:
+        os.environ["AIX_COUNT23_VIA_K1"] = "0"
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(a, sys.argv[1:]))        # child processes; this one never touches the GPU
     world_env = int(os.environ.get("WORLD_SIZE", 1))
@@ -1063,20 +1066,24 @@ def main():
         digest = tf_checksum(tf)
         _, kern_ms, _ = timed_steps(lambda: ix.count23_fixed_t(reads, _lib.CANON_TRUE_RC, tf), 3, 0, dev)     # the kernel alone
         windows = a.reads * (150 - 22)
+        backend_ran = ix.info["count23_backend"]                        # of the timed calls (the CPU-baseline leg below counts a short sample through another one)
+        roof23 = count23_roofline(ix, windows, a.reads, kern_ms)
         cb23 = cpu_baseline_count23(ix, g, pf, dev, cache) if (rank == 0 and world == 1 and not a.no_cpu_baseline) else None
         out.update({**({"cpu_baseline": cb23} if cb23 else {}),
                     "metric": "reads_per_sec_23mer_count_fixed_mphf", "value": world * a.reads * a.steps / wall, "unit": "reads/s",
                     "ms_per_step": wall / a.steps * 1e3, "dtype": "u64",
                     "config": {"workload": "configs[3]-shaped: 23-mer histogram against a fixed MPHF, 150 bp reads, + all-reduce(sum) of tf[]; per-rank reads fixed (weak)",
-                               "reads_per_step_per_gpu": a.reads, "index_keys": ix.n},
+                               "reads_per_step_per_gpu": a.reads, "index_keys": ix.n,
+                               "counting_backend": {1: "memory-side atomics", 2: "slot stream + LDS histogram",
+                                                    3: "distinct k-mers first (K1), one probe per distinct k-mer"}.get(backend_ran, "none")},
                     "tf_digest": digest,
-                    "roofline": {**count23_roofline(ix, windows, a.reads, kern_ms),
+                    "roofline": {**roof23,
                                  "calls_in_process": a.steps + a.warmup + 3 + (1 if cb23 else 0)}})      # for the per-call normalisation of the PMC passes
-        tr = load_pmc_traffic("count23", reads_per_launch=a.reads)
+        tr = load_pmc_traffic("count23", reads_per_launch=a.reads) if backend_ran == 2 else None      # the PMC passes profile the probe path (--probe-path)
         if tr:
             out["roofline"]["traffic"] = tr.get("bytes_per_launch")
             out["roofline"]["traffic_source"] = tr.get("source")
-        if not a.no_gather_probe:
+        if not a.no_gather_probe and backend_ran != 3:                   # (back end 3 reads no table line per window)
             peak_acc = gather_roofline(dev)
             acc = out["roofline"]["lines_per_window"]
             ach = windows * acc / (kern_ms * 1e-3)

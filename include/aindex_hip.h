@@ -66,7 +66,7 @@ typedef struct {
     uint64_t minimizer_unfiled_keys; /* keys whose chain of lines was full (answered by the hash-keyed table) */
     uint32_t count23_backend; /* the last aix_count23_fixed* call on this handle: 0 none yet, 1 memory-side atomics (short buffers,
                                  AIX_COUNT23_ATOMICS=1), 2 slot stream + LDS histogram, 3 distinct k-mers of the reads first (K1), one
-                                 probe per distinct k-mer (buffers of >= 2^31 windows holding >= 64 windows per key; AIX_COUNT23_VIA_K1) */
+                                 probe per distinct k-mer (buffers of >= 2^29 windows holding >= 8 windows per key; AIX_COUNT23_VIA_K1) */
     uint32_t count23_passes;  /* back end 2: passes over the slot stream = ceil(n / 2^26)                                           */
     uint32_t positions_backend; /* the last aix_positions_fill* call: bit 0 = a piece was grouped by the stable radix sort (short buffers, more than
                                    2^30 slots, workspace did not fit), bit 1 = by the MSD partition; 0 none yet                    */

@@ -12,7 +12,7 @@ Q="--no-cpu-baseline --no-secondary --no-gather-probe"
 TAGS=(
  "l23rand|--workload lookup23"
  "l23mix|--workload lookup23 --query-mix"
- "c23|--workload count23 --reads 10000000"
+ "c23|--workload count23 --reads 10000000 --probe-path"
  "cov23|--workload coverage23"
  "pos23|--workload positions23 --reads 5000000"
  "dist23|--workload distinct23 --reads 5000000"
@@ -34,14 +34,14 @@ fi
 if [ "$PART" = "A2" ]; then
 step "workloads"
 for w in "lookup23 --query-mix --cpu-sample 2000000 --no-secondary" "lookup23 --no-bucket-table $Q" "lookup23 --no-absence-filter $Q" "lookup23 --query-mix --no-bucket-table $Q" \
-         "lookup23 --gpu-builder $Q" "lookup13" "count13" "count23 --reads 10000000" "count23 --reads 10000000 --no-bucket-table --no-cpu-baseline" \
+         "lookup23 --gpu-builder $Q" "lookup13" "count13" "count23 --reads 10000000" "count23 --reads 10000000 --probe-path --no-cpu-baseline" "count23 --reads 10000000 --no-bucket-table --probe-path --no-cpu-baseline" \
          "coverage23" "coverage23 --no-bucket-table --seqs 100000 --no-cpu-baseline" "coverage13" "distinct23 --reads 5000000" "positions23 --reads 5000000" "normalize --reads 5000000" \
          "e2e13" "e2e23"; do
-  n=$(echo $w | sed "s/--no-cpu-baseline//; s/--no-secondary//; s/--no-gather-probe//; s/--cpu-sample 2000000//" | tr -d ' -'); timeout -k 10 600 python bench.py --workload $w --steps 5 --warmup 1 > $O/bench_$n.json 2> $O/bench_$n.err || { echo "$w failed"; tail -10 $O/bench_$n.err; exit 6; }
+  n=$(echo $w | sed "s/--no-cpu-baseline//; s/--probe-path/probepath/; s/--no-secondary//; s/--no-gather-probe//; s/--cpu-sample 2000000//" | tr -d ' -'); timeout -k 10 600 python bench.py --workload $w --steps 5 --warmup 1 > $O/bench_$n.json 2> $O/bench_$n.err || { echo "$w failed"; tail -10 $O/bench_$n.err; exit 6; }
 done
 timeout -k 10 600 python bench.py --workload distinct23 --reads 200000000 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_distinct23reads200000000.json 2> $O/bench_distinct23reads200000000.err || exit 6
 AIX_COUNT23_ATOMICS=1 timeout -k 10 600 python bench.py --workload count23 --reads 10000000 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_count23_atomics.json 2> /dev/null || exit 6
-AIX_COUNT23_RUN=16 timeout -k 10 600 python bench.py --workload count23 --reads 10000000 --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_count23_run16.json 2> /dev/null || exit 6
+AIX_COUNT23_RUN=16 timeout -k 10 600 python bench.py --workload count23 --reads 10000000 --probe-path --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_count23_run16.json 2> /dev/null || exit 6
 AIX_COUNT13_ATOMICS=1 timeout -k 10 600 python bench.py --workload count13 --steps 3 --warmup 1 > $O/bench_count13_atomics.json 2> /dev/null || exit 6
 python - <<PY
 import json,glob
